@@ -1,0 +1,435 @@
+"""Host-side graph -> PHMM parameter builders (numpy, no device work).
+
+Mirrors the reference's caller-side adapters so that tests read like the reference's:
+
+* ``SeqGraph.to_phmm / to_uniform_phmm / to_non_zero_phmm``
+  -- /root/reference/src/graph/seq_graph.rs:160-273
+* ``GenomeGraph.to_seq_graph`` -- src/graph/genome_graph.rs:252-397 (forward strand)
+* mocks -- src/graph/mocks.rs:8-62, src/hmmv2/mocks.rs:27-54, src/multi_dbg/toy.rs:260-303
+* ``dbg_from_haplotypes`` -- the k-mer graph -> node-centric graph of
+  src/multi_dbg.rs:1370-1409, 1551-1604 (PHMM node = k-mer, emission = last base,
+  no edges through the all-``n`` terminal), built from true genome k-mers with true
+  copy numbers.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .params import PHMMParams
+
+NULL_BASE = ord("n")  # src/common.rs NULL_BASE
+
+
+def _ln(x: float) -> float:
+    return math.log(x) if x > 0 else -math.inf
+
+
+@dataclass
+class PHMMArrays:
+    """Flat PHMMModel (src/hmmv2/common.rs:61-64): the arrays that cross the C ABI."""
+
+    param: PHMMParams
+    emission: np.ndarray  # u8[N]
+    init_logp: np.ndarray  # f64[N]
+    edge_src: np.ndarray  # u32[E]
+    edge_dst: np.ndarray  # u32[E]
+    trans_logp: np.ndarray  # f64[E]
+    is_emittable: Optional[np.ndarray] = None  # bool[N]
+
+    @property
+    def n_nodes(self) -> int:
+        return int(self.emission.shape[0])
+
+    @property
+    def n_edges(self) -> int:
+        return int(self.edge_src.shape[0])
+
+
+@dataclass
+class SeqGraph:
+    """DiGraph<N: SeqNode, E: SeqEdge> (src/graph/seq_graph.rs): one node per base."""
+
+    copy_num: np.ndarray  # i64[N]
+    base: np.ndarray  # u8[N]
+    edge_src: np.ndarray  # u32[E]
+    edge_dst: np.ndarray  # u32[E]
+    edge_copy_num: Optional[np.ndarray] = None  # i64[E], -1 = None
+
+    def is_emittable(self) -> np.ndarray:
+        return self.base != NULL_BASE
+
+    # seq_graph.rs:160-223
+    def _to_phmm(self, param: PHMMParams, min_copy_num: int) -> PHMMArrays:
+        n = self.base.shape[0]
+        emit = self.is_emittable()
+        cn = np.maximum(self.copy_num, min_copy_num)
+        total = int(np.where(emit, cn, 0).sum())
+        init = np.full(n, -np.inf)
+        with np.errstate(divide="ignore"):
+            init[emit] = np.log(cn[emit].astype(np.float64)) - math.log(total) if total > 0 else -np.inf
+        e = self.edge_src.shape[0]
+        trans = np.full(e, -np.inf)
+        # total emittable child copy number per parent (seq_graph.rs:124-135)
+        child_cn = np.where(emit[self.edge_dst], cn[self.edge_dst], 0)
+        tot_child = np.zeros(n, dtype=np.int64)
+        np.add.at(tot_child, self.edge_src, child_cn)
+        for j in range(e):
+            s, d = int(self.edge_src[j]), int(self.edge_dst[j])
+            ecn = -1 if self.edge_copy_num is None else int(self.edge_copy_num[j])
+            if ecn >= 0:  # seq_graph.rs:185-197
+                if emit[d] and ecn > 0:
+                    assert self.copy_num[s] > 0
+                    trans[j] = _ln(ecn / int(self.copy_num[s]))
+            else:  # seq_graph.rs:198-209
+                if emit[d] and tot_child[s] > 0:
+                    trans[j] = _ln(int(cn[d]) / int(tot_child[s]))
+        return PHMMArrays(param, self.base.astype(np.uint8), init, self.edge_src.astype(np.uint32),
+                          self.edge_dst.astype(np.uint32), trans, emit.copy())
+
+    def to_phmm(self, param: PHMMParams) -> PHMMArrays:
+        return self._to_phmm(param, 0)
+
+    def to_non_zero_phmm(self, param: PHMMParams) -> PHMMArrays:
+        """seq_graph.rs:263-273 (copy numbers clamped to >= 1; used for mapping)."""
+        return self._to_phmm(param, 1)
+
+    def to_uniform_phmm(self, param: PHMMParams) -> PHMMArrays:
+        """seq_graph.rs:224-262"""
+        n = self.base.shape[0]
+        emit = self.is_emittable()
+        n_emit = int(emit.sum())
+        init = np.where(emit, -math.log(n_emit) if n_emit else -np.inf, -np.inf).astype(np.float64)
+        n_child = np.zeros(n, dtype=np.int64)
+        np.add.at(n_child, self.edge_src, emit[self.edge_dst].astype(np.int64))
+        with np.errstate(divide="ignore"):
+            trans = np.where(emit[self.edge_dst], -np.log(n_child[self.edge_src].astype(np.float64)), -np.inf)
+        return PHMMArrays(param, self.base.astype(np.uint8), init, self.edge_src.astype(np.uint32),
+                          self.edge_dst.astype(np.uint32), trans.astype(np.float64), emit.copy())
+
+
+def vectorised_to_phmm(sg: SeqGraph, param: PHMMParams, min_copy_num: int = 0) -> PHMMArrays:
+    """Same result as ``SeqGraph._to_phmm`` for graphs without edge copy numbers,
+    without the per-edge Python loop (used for 1e5..1e6-node synthetic DBGs)."""
+    assert sg.edge_copy_num is None
+    n = sg.base.shape[0]
+    emit = sg.is_emittable()
+    cn = np.maximum(sg.copy_num, min_copy_num)
+    total = int(np.where(emit, cn, 0).sum())
+    init = np.full(n, -np.inf)
+    init[emit] = np.log(cn[emit].astype(np.float64)) - math.log(total)
+    child_cn = np.where(emit[sg.edge_dst], cn[sg.edge_dst], 0)
+    tot_child = np.zeros(n, dtype=np.int64)
+    np.add.at(tot_child, sg.edge_src, child_cn)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        trans = np.where((child_cn > 0) & (tot_child[sg.edge_src] > 0),
+                         np.log(child_cn.astype(np.float64) / tot_child[sg.edge_src].astype(np.float64)),
+                         -np.inf)
+    return PHMMArrays(param, sg.base.astype(np.uint8), init, sg.edge_src.astype(np.uint32),
+                      sg.edge_dst.astype(np.uint32), trans, emit.copy())
+
+
+# ---------------------------------------------------------------- genome graph / mocks
+
+def genome_graph_to_seq_graph(seqs: Sequence[bytes], copy_nums: Sequence[int],
+                              edges: Sequence[Tuple[int, int, Optional[int]]] = ()) -> SeqGraph:
+    """genome_graph.rs:252-397: each GenomeNode (sequence, copy number) becomes a chain of
+    one-base nodes whose internal edges carry Some(copy_num); GenomeEdges connect tail->head."""
+    base: List[int] = []
+    cn: List[int] = []
+    es: List[int] = []
+    ed: List[int] = []
+    ec: List[int] = []
+    heads, tails = [], []
+    for seq, c in zip(seqs, copy_nums):
+        start = len(base)
+        for b in seq:
+            base.append(b)
+            cn.append(c)
+        for j in range(len(seq) - 1):
+            es.append(start + j)
+            ed.append(start + j + 1)
+            ec.append(c)
+        heads.append(start)
+        tails.append(start + len(seq) - 1)
+    for (s, t, c) in edges:
+        es.append(tails[s])
+        ed.append(heads[t])
+        ec.append(-1 if c is None else c)
+    return SeqGraph(np.array(cn, dtype=np.int64), np.array(base, dtype=np.uint8),
+                    np.array(es, dtype=np.uint32), np.array(ed, dtype=np.uint32),
+                    np.array(ec, dtype=np.int64))
+
+
+def mock_linear() -> SeqGraph:
+    """graph/mocks.rs:8-12"""
+    return genome_graph_to_seq_graph([b"ATTCGATCGT"], [1])
+
+
+def mock_linear_from(seq: bytes) -> SeqGraph:
+    return genome_graph_to_seq_graph([seq], [1])
+
+
+def mock_crossing(has_edge_copy_number: bool) -> SeqGraph:
+    """graph/mocks.rs:44-62 with the sequences its own test pins (mocks.rs:81-84)."""
+    seqs = [b"TGCTCTGGCG", b"ATTAGGAGCA", b"GCTGATAGGG", b"CGAAGATGAG"]
+    if has_edge_copy_number:
+        edges = [(0, 2, 2), (1, 2, 0), (0, 3, 0), (1, 3, 2)]
+    else:
+        edges = [(0, 2, None), (1, 2, None), (0, 3, None), (1, 3, None)]
+    return genome_graph_to_seq_graph(seqs, [2, 2, 2, 2], edges)
+
+
+def node_centric_from_dbg(node_is_terminal: Sequence[bool],
+                          edges: Sequence[Tuple[int, int, int, int]]) -> SeqGraph:
+    """MultiDbg::to_node_centric_graph with add_terminal=false (multi_dbg.rs:1551-1604):
+    DBG edge (k-mer; src node, dst node, base, copy_num) -> PHMM node; for each
+    non-terminal DBG node, parents x childs (petgraph order: newest edge first)."""
+    n_nodes = len(node_is_terminal)
+    incoming: List[List[int]] = [[] for _ in range(n_nodes)]
+    outgoing: List[List[int]] = [[] for _ in range(n_nodes)]
+    for e, (s, t, _b, _c) in enumerate(edges):
+        outgoing[s].append(e)
+        incoming[t].append(e)
+    es, ed = [], []
+    for v in range(n_nodes):
+        if node_is_terminal[v]:
+            continue
+        for e1 in reversed(incoming[v]):
+            for e2 in reversed(outgoing[v]):
+                es.append(e1)
+                ed.append(e2)
+    return SeqGraph(np.array([c for (_, _, _, c) in edges], dtype=np.int64),
+                    np.array([b for (_, _, b, _) in edges], dtype=np.uint8),
+                    np.array(es, dtype=np.uint32), np.array(ed, dtype=np.uint32), None)
+
+
+def toy_repeat() -> Tuple[SeqGraph, int]:
+    """multi_dbg/toy.rs:260-303 (k=4): returns (node-centric graph, k)."""
+    term = [True] + [False] * 13
+    (nnn, nnt, ntc, tcc, ccc, cca, cag, agc, gca, agg, gga, gaa, aan, ann) = range(14)
+    o = ord
+    edges = [
+        (nnn, nnt, o("T"), 1), (nnt, ntc, o("C"), 1), (ntc, tcc, o("C"), 1), (tcc, ccc, o("C"), 1),
+        (ccc, cca, o("A"), 1), (cca, cag, o("G"), 1),
+        (cag, agc, o("C"), 3), (agc, gca, o("A"), 3), (gca, cag, o("G"), 3),
+        (cag, agg, o("G"), 1), (agg, gga, o("A"), 1), (gga, gaa, o("A"), 1),
+        (gaa, aan, o("n"), 1), (aan, ann, o("n"), 1), (ann, nnn, o("n"), 1),
+    ]
+    return node_centric_from_dbg(term, edges), 4
+
+
+# ---------------------------------------------------------------- synthetic genomes / DBG
+
+_B = np.uint64(0x9E3779B97F4A7C15)  # odd multiplier for the rolling hash
+_ENC = np.full(256, 4, dtype=np.uint64)
+for _i, _c in enumerate(b"ACGT"):
+    _ENC[_c] = _i
+
+
+def random_genome(length: int, seed: int) -> np.ndarray:
+    """i.i.d. uniform ACGT (random_seq.rs:9-18 semantics; our own PRNG stream)."""
+    rng = np.random.default_rng(seed)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=length)]
+
+
+def diverge(hap: np.ndarray, rate: float, seed: int) -> np.ndarray:
+    """second haplotype: per-base divergence split evenly sub/ins/del
+    (random_seq.rs:131-139; genome.rs:177-185)."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    u = rng.random(hap.shape[0])
+    kind = rng.integers(0, 3, size=hap.shape[0])
+    rnd = rng.integers(0, 4, size=hap.shape[0])
+    for i, b in enumerate(hap.tolist()):
+        if u[i] >= rate:
+            out.append(b)
+        elif kind[i] == 0:  # substitution to a different base
+            c = int(acgt[rnd[i]])
+            if c == b:
+                c = int(acgt[(rnd[i] + 1) % 4])
+            out.append(c)
+        elif kind[i] == 1:  # insertion after
+            out.append(b)
+            out.append(int(acgt[rnd[i]]))
+        # deletion: skip
+    return np.array(out, dtype=np.uint8)
+
+
+def _window_hashes(enc: np.ndarray, w: int) -> np.ndarray:
+    """polynomial hash (mod 2^64) of every length-w window of enc (uint64 codes)."""
+    n = enc.shape[0]
+    pw = np.ones(w + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for j in range(1, w + 1):
+            pw[j] = pw[j - 1] * _B
+        # prefix hash H[i+1] = H[i]*B + (enc[i]+1) done blockwise via powers
+        # (explicit loop is O(n) python; use cumulative trick with power table instead)
+        # H[i] = sum_{j<i} (enc[j]+1) * B^(i-1-j)  -> window = H[i+w] - H[i]*B^w
+        H = np.zeros(n + 1, dtype=np.uint64)
+        v = enc + np.uint64(1)
+        # iterative doubling is overkill; a simple chunked python loop is fast enough
+        acc = np.uint64(0)
+        Hl = H
+        for i in range(n):
+            acc = acc * _B + v[i]
+            Hl[i + 1] = acc
+        return Hl[w:] - Hl[:-w] * pw[w]
+
+
+def dbg_from_haplotypes(haps: Sequence[np.ndarray], k: int) -> SeqGraph:
+    """k-mer graph of the haplotypes with k-1 leading/trailing ``n`` pads
+    (kmer/kmer.rs:60-75) as a node-centric SeqGraph: node = distinct k-mer,
+    copy number = multiplicity, base = last base, edge u->v iff suffix_{k-1}(u) ==
+    prefix_{k-1}(v) and that (k-1)-mer is not the all-``n`` terminal
+    (multi_dbg.rs:1388, 1580-1591).  Nodes are numbered by first occurrence along the
+    haplotypes, so unitigs are contiguous runs of ids."""
+    pads = np.full(k - 1, NULL_BASE, dtype=np.uint8)
+    km_hash, pre_hash, suf_hash, last_base, windows = [], [], [], [], []
+    for h in haps:
+        a = np.concatenate([pads, np.asarray(h, dtype=np.uint8), pads])
+        enc = _ENC[a]
+        hk = _window_hashes(enc, k)
+        hk1 = _window_hashes(enc, k - 1)
+        nk = hk.shape[0]
+        km_hash.append(hk)
+        pre_hash.append(hk1[:nk])
+        suf_hash.append(hk1[1:nk + 1])
+        last_base.append(a[k - 1:k - 1 + nk])
+        windows.append(np.lib.stride_tricks.sliding_window_view(a, k))
+    km = np.concatenate(km_hash)
+    pre = np.concatenate(pre_hash)
+    suf = np.concatenate(suf_hash)
+    lb = np.concatenate(last_base)
+    win = np.concatenate(windows) if len(windows) > 1 else windows[0]
+    uniq, first, inv, counts = np.unique(km, return_index=True, return_inverse=True, return_counts=True)
+    order = np.argsort(first, kind="stable")  # unique-id -> rank by first occurrence
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.shape[0])
+    node_of_occ = rank[inv]
+    n = uniq.shape[0]
+    first_occ = first[order]
+    # verify there was no hash collision: every occurrence equals its representative
+    rep = win[first_occ]
+    step = 1 << 18
+    for s in range(0, win.shape[0], step):
+        blk = slice(s, min(s + step, win.shape[0]))
+        if not np.array_equal(win[blk], rep[node_of_occ[blk]]):
+            raise RuntimeError("k-mer hash collision; change the hash multiplier")
+    copy_num = counts[order].astype(np.int64)
+    base = lb[first_occ]
+    npre = pre[first_occ]
+    nsuf = suf[first_occ]
+    with np.errstate(over="ignore"):
+        term = _window_hashes(np.full(k - 1, 4, dtype=np.uint64), k - 1)[0]
+    # edges: join suffix(u) == prefix(v)
+    porder = np.argsort(npre, kind="stable")
+    ps = npre[porder]
+    lo = np.searchsorted(ps, nsuf, side="left")
+    hi = np.searchsorted(ps, nsuf, side="right")
+    cnt = np.where(nsuf == term, 0, hi - lo)
+    src = np.repeat(np.arange(n, dtype=np.int64), cnt)
+    offs = np.concatenate([[0], np.cumsum(cnt)])
+    within = np.arange(src.shape[0]) - offs[src]
+    dst = porder[lo[src] + within]
+    return SeqGraph(copy_num, base.astype(np.uint8), src.astype(np.uint32), dst.astype(np.uint32), None)
+
+
+# ---------------------------------------------------------------- read sampling
+
+def sample_reads(model: PHMMArrays, n_bases_total: int, state_count: int, seed: int,
+                 max_reads: Optional[int] = None) -> List[bytes]:
+    """Reads drawn from the PHMM generative model itself (src/hmmv2/sample.rs:270-419):
+    Begin -> pick_init_node by init_prob; {Match,Ins,Del} transitions by param; Match emits
+    the node base with p_match else one of the other three, Ins emits uniform ACGT; stop after
+    ``state_count`` transitions (ReadLength::StateCount) or when no child has p>0.  Reads
+    are sampled until ``n_bases_total`` bases (sample.rs:223-232).  Our own PRNG stream."""
+    p = model.param
+    rng = np.random.default_rng(seed)
+    n = model.n_nodes
+    # children CSR with linear trans probs
+    order = np.argsort(model.edge_src, kind="stable")
+    csrc = model.edge_src[order]
+    cdst = model.edge_dst[order]
+    cpr = np.exp(model.trans_logp[order])
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(off, csrc.astype(np.int64) + 1, 1)
+    off = np.cumsum(off)
+    init = np.exp(model.init_logp)
+    init_cdf = np.cumsum(init / init.sum())
+    e = math.exp
+    tr = {
+        "M": (e(p.p_MM), e(p.p_MI), e(p.p_MD)),
+        "I": (e(p.p_IM), e(p.p_II), e(p.p_ID)),
+        "D": (e(p.p_DM), e(p.p_DI), e(p.p_DD)),
+    }
+    pm = e(p.p_match)
+    acgt = b"ACGT"
+    reads: List[bytes] = []
+    total = 0
+
+    def pick_child(v: int) -> int:
+        a, b = off[v], off[v + 1]
+        w = cpr[a:b]
+        s = w.sum()
+        if b == a or s <= 0:
+            return -1
+        if b - a == 1:
+            return int(cdst[a])
+        u = rng.random() * s
+        c = np.cumsum(w)
+        return int(cdst[a + int(np.searchsorted(c, u, side="right").clip(0, b - a - 1))])
+
+    def emit_match(v: int) -> int:
+        b = int(model.emission[v])
+        if rng.random() < pm:
+            return b
+        others = [c for c in acgt if c != b]
+        return others[int(rng.integers(0, len(others)))]
+
+    while total < n_bases_total and (max_reads is None or len(reads) < max_reads):
+        out = bytearray()
+        # MatchBegin (sample.rs:389-401)
+        node = int(np.searchsorted(init_cdf, rng.random(), side="right").clip(0, n - 1))
+        state = "B"
+        n_state = 0
+        while n_state < state_count:
+            if state in ("B", "IB"):
+                pm_, pi_, pd_ = (tr["M"] if state == "B" else tr["I"])
+                u = rng.random() * (pm_ + pi_ + pd_)
+                if u < pi_:
+                    state = "IB"
+                    out.append(acgt[int(rng.integers(0, 4))])
+                elif u < pi_ + pm_:
+                    state = "M"
+                    out.append(emit_match(node))
+                else:
+                    state = "D"
+                if state == "IB":
+                    node = int(np.searchsorted(init_cdf, rng.random(), side="right").clip(0, n - 1))
+            else:
+                child = pick_child(node)
+                if child < 0:
+                    break
+                pm_, pi_, pd_ = tr[state]
+                u = rng.random() * (pm_ + pi_ + pd_)
+                if u < pm_:
+                    state = "M"
+                    node = child
+                    out.append(emit_match(node))
+                elif u < pm_ + pi_:
+                    state = "I"
+                    out.append(acgt[int(rng.integers(0, 4))])
+                else:
+                    state = "D"
+                    node = child
+            n_state += 1
+        if len(out) == 0:
+            continue
+        reads.append(bytes(out))
+        total += len(out)
+    return reads
