@@ -1,0 +1,298 @@
+// extern "C" surface of libphmm_amd.so (include/phmm_amd.h).  Argument validation mirrors
+// the reference's asserts/panics; nothing throws across the ABI.
+#include <cmath>
+#include <cstring>
+
+#include "phmm_internal.h"
+
+namespace phmm {
+
+static thread_local std::string g_error;
+static thread_local hipStream_t g_stream = nullptr;
+static thread_local uint64_t g_ws_limit = 0;
+static thread_local CallStats g_stats;
+static thread_local bool g_timing = false;
+
+void set_error(const std::string &msg) { g_error = msg; }
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+hipStream_t current_stream() { return g_stream; }
+CallStats &stats() { return g_stats; }
+bool timing_enabled() { return g_timing; }
+
+uint64_t workspace_limit() {
+    if (g_ws_limit) return g_ws_limit;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)16 << 30;
+    return (uint64_t)(0.8 * (double)fr);
+}
+
+void copy_out(void *dst, const void *src_dev, size_t bytes) {
+    if (!dst || !bytes) return;
+    hipPointerAttribute_t at;
+    const bool dev = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeDevice;
+    if (!dev) (void)hipGetLastError();
+    HIP_CHECK(hipMemcpyAsync(dst, src_dev, bytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                             current_stream()));
+    HIP_CHECK(hipStreamSynchronize(current_stream()));
+}
+
+template <class F> static int guarded(F &&f) {
+    try {
+        f();
+        return PHMM_OK;
+    } catch (const Error &e) {
+        return fail(e.code, e.msg);
+    } catch (const std::bad_alloc &) {
+        return fail(PHMM_ENOMEM, "host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(PHMM_EINTERNAL, e.what());
+    } catch (...) {
+        return fail(PHMM_EINTERNAL, "unknown error");
+    }
+}
+
+static void check_params(const phmm_params *p) {
+    if (!p) PHMM_THROW(PHMM_EINVAL, "params is NULL");
+    // params.rs:81-83
+    if (p->n_active_nodes <= 0) PHMM_THROW(PHMM_EINVAL, "n_active_nodes must be > 0");
+    if (p->n_warmup <= 0) PHMM_THROW(PHMM_EINVAL, "n_warmup must be > 0");
+    if (p->n_active_nodes >= PHMM_MAX_ACTIVE_NODES)
+        PHMM_THROW(PHMM_EINVAL, "n_active_nodes must be < MAX_ACTIVE_NODES (400)");
+    if (p->n_max_gaps < 0 || p->n_max_gaps > PHMM_MAX_GAPS)
+        PHMM_THROW(PHMM_EINVAL, "n_max_gaps out of the supported range [0, 6]");
+    const double *lp = &p->p_mismatch;
+    for (int i = 0; i < 15; i++)
+        if (std::isnan(lp[i]) || lp[i] > 1e-12) PHMM_THROW(PHMM_EINVAL, "params: log-probability > 0 or NaN");
+}
+
+static void require_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        PHMM_THROW(PHMM_ENODEVICE, "no HIP device: the MI355X path has no CPU fallback");
+    }
+}
+
+}  // namespace phmm
+
+using namespace phmm;
+
+extern "C" {
+
+const char *phmm_last_error(void) { return g_error.c_str(); }
+const char *phmm_version(void) { return "dbgphmm_amd 0.1.0 gfx950"; }
+
+int phmm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+int phmm_set_device(int device) {
+    return guarded([&] {
+        require_device();
+        HIP_CHECK(hipSetDevice(device));
+    });
+}
+int phmm_set_stream(void *s) {
+    g_stream = (hipStream_t)s;
+    return PHMM_OK;
+}
+int phmm_set_workspace_limit(uint64_t bytes) {
+    g_ws_limit = bytes;
+    return PHMM_OK;
+}
+int phmm_enable_timing(int on) {
+    g_timing = on != 0;
+    return PHMM_OK;
+}
+int phmm_last_call_stats(int which, double *ms, uint64_t *launches, uint64_t *cells) {
+    if (which < 0 || which > 3) return fail(PHMM_EINVAL, "which out of range");
+    if (ms) *ms = g_stats.ms[which];
+    if (launches) *launches = g_stats.launches[which];
+    if (cells) *cells = g_stats.cells[which];
+    return PHMM_OK;
+}
+
+static double lnz(double x) { return x > 0.0 ? std::log(x) : -INFINITY; }
+
+int phmm_params_new(double p_mismatch, double p_gap_open, double p_gap_ext, double p_end,
+                    int64_t n_active_nodes, int64_t n_warmup, phmm_params *o) {
+    return guarded([&] {
+        if (!o) PHMM_THROW(PHMM_EINVAL, "out is NULL");
+        // params.rs:73-113
+        o->p_mismatch = lnz(p_mismatch);
+        o->p_gap_open = lnz(p_gap_open);
+        o->p_gap_ext = lnz(p_gap_ext);
+        o->p_end = lnz(p_end);
+        o->p_DD = o->p_II = o->p_gap_ext;
+        o->p_MI = o->p_MD = o->p_ID = o->p_DI = o->p_gap_open;
+        const double go = std::exp(o->p_gap_open), ge = std::exp(o->p_gap_ext), pe = std::exp(o->p_end);
+        o->p_MM = lnz(1.0 - 2.0 * go - pe);
+        o->p_DM = o->p_IM = lnz(1.0 - go - ge - pe);
+        o->p_match = lnz(1.0 - std::exp(o->p_mismatch));
+        o->p_random = std::log(0.25);
+        o->n_active_nodes = n_active_nodes;
+        o->active_node_max_ratio = 30.0;
+        o->n_warmup = n_warmup;
+        o->n_max_gaps = 4;
+        o->warmup_threshold = PHMM_MAX_ACTIVE_NODES / 2;
+        check_params(o);
+    });
+}
+int phmm_params_uniform(double p, phmm_params *o) { return phmm_params_new(p, p, p, 0.00001, 40, 50, o); }
+
+int phmm_model_create(uint32_t N, uint32_t E, const uint8_t *emission, const double *init_logp,
+                      const uint32_t *esrc, const uint32_t *edst, const double *trans_logp,
+                      const phmm_params *params, phmm_model **out) {
+    phmm_model *m = nullptr;
+    int rc = guarded([&] {
+        if (!out) PHMM_THROW(PHMM_EINVAL, "out is NULL");
+        *out = nullptr;
+        if (N == 0) PHMM_THROW(PHMM_EINVAL, "model has no nodes");
+        if (!emission || !init_logp || (E && (!esrc || !edst || !trans_logp)))
+            PHMM_THROW(PHMM_EINVAL, "NULL model array");
+        check_params(params);
+        for (uint32_t e = 0; e < E; e++)
+            if (esrc[e] >= N || edst[e] >= N) PHMM_THROW(PHMM_EINVAL, "edge endpoint out of range");
+        for (uint32_t v = 0; v < N; v++)
+            if (std::isnan(init_logp[v]) || init_logp[v] > 1e-9) PHMM_THROW(PHMM_EINVAL, "init_logp > 0 or NaN");
+        for (uint32_t e = 0; e < E; e++)
+            if (std::isnan(trans_logp[e]) || trans_logp[e] > 1e-9) PHMM_THROW(PHMM_EINVAL, "trans_logp > 0 or NaN");
+        require_device();
+        m = new phmm_model();
+        m->N = N;
+        m->E = E;
+        m->params = *params;
+        m->emission.assign(emission, emission + N);
+        m->init_logp.assign(init_logp, init_logp + N);
+        m->esrc.assign(esrc, esrc + E);
+        m->edst.assign(edst, edst + E);
+        m->trans_logp.assign(trans_logp, trans_logp + E);
+        model_build_host(m);
+        model_upload(m);
+        *out = m;
+    });
+    if (rc != PHMM_OK) delete m;
+    return rc;
+}
+
+int phmm_model_set_probs(phmm_model *m, const double *init_logp, const double *trans_logp) {
+    return guarded([&] {
+        if (!m || !init_logp || (m->E && !trans_logp)) PHMM_THROW(PHMM_EINVAL, "NULL argument");
+        m->init_logp.assign(init_logp, init_logp + m->N);
+        m->trans_logp.assign(trans_logp, trans_logp + m->E);
+        model_upload(m);
+    });
+}
+int phmm_model_set_params(phmm_model *m, const phmm_params *params) {
+    return guarded([&] {
+        if (!m) PHMM_THROW(PHMM_EINVAL, "NULL model");
+        check_params(params);
+        m->params = *params;
+        model_build_host(m);
+        model_upload(m);
+    });
+}
+uint32_t phmm_model_n_nodes(const phmm_model *m) { return m ? m->N : 0; }
+uint32_t phmm_model_n_edges(const phmm_model *m) { return m ? m->E : 0; }
+void phmm_model_destroy(phmm_model *m) { delete m; }
+
+int phmm_reads_create(const uint8_t *bases, const uint64_t *offsets, uint64_t R, phmm_reads **out) {
+    phmm_reads *r = nullptr;
+    int rc = guarded([&] {
+        if (!out) PHMM_THROW(PHMM_EINVAL, "out is NULL");
+        *out = nullptr;
+        if (!offsets || (R && !bases)) PHMM_THROW(PHMM_EINVAL, "NULL argument");
+        if (offsets[0] != 0) PHMM_THROW(PHMM_EINVAL, "offsets[0] must be 0");
+        r = new phmm_reads();
+        r->R = R;
+        r->off.assign(offsets, offsets + R + 1);
+        for (uint64_t i = 0; i < R; i++) {
+            if (offsets[i + 1] <= offsets[i])
+                PHMM_THROW(PHMM_EINVAL, "empty read (the reference panics in last_table()) or offsets not increasing");
+            r->max_len = std::max<uint64_t>(r->max_len, offsets[i + 1] - offsets[i]);
+        }
+        if (r->max_len > (uint64_t)1 << 30) PHMM_THROW(PHMM_EINVAL, "read longer than 2^30 bases");
+        r->total = offsets[R];
+        r->bases.assign(bases, bases + r->total);
+        *out = r;
+    });
+    if (rc != PHMM_OK) delete r;
+    return rc;
+}
+uint64_t phmm_reads_count(const phmm_reads *r) { return r ? r->R : 0; }
+uint64_t phmm_reads_total_bases(const phmm_reads *r) { return r ? r->total : 0; }
+void phmm_reads_destroy(phmm_reads *r) { delete r; }
+
+int phmm_run_dense(phmm_model *m, const phmm_reads *reads, double *lf, double *lb, double *nf) {
+    return guarded([&] {
+        if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
+        if (reads->R == 0) {
+            if (nf) {
+                std::vector<double> z(m->N, 0.0);
+                DevBuf b;
+                b.upload(z.data(), z.size() * sizeof(double));
+                copy_out(nf, b.p, z.size() * sizeof(double));
+            }
+            return;
+        }
+        run_dense(m, reads, lf, lb, nf);
+    });
+}
+
+int phmm_dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i, double *f_d,
+                      double *f_scal, double *b_m, double *b_i, double *b_d, double *b_scal) {
+    return guarded([&] {
+        if (!m || !read) PHMM_THROW(PHMM_EINVAL, "NULL model or read");
+        if (len == 0) PHMM_THROW(PHMM_EINVAL, "empty read");
+        dense_tables(m, read, len, f_m, f_i, f_d, f_scal, b_m, b_i, b_d, b_scal);
+    });
+}
+
+int phmm_mappings_create(const phmm_reads *reads, const uint64_t *pos_off, const uint32_t *nodes,
+                         const double *logp, phmm_mappings **out) {
+    phmm_mappings *mp = nullptr;
+    int rc = guarded([&] {
+        if (!out) PHMM_THROW(PHMM_EINVAL, "out is NULL");
+        *out = nullptr;
+        if (!reads || !pos_off) PHMM_THROW(PHMM_EINVAL, "NULL argument");
+        mp = new phmm_mappings();
+        mp->R = reads->R;
+        mp->total_pos = reads->total;
+        mp->read_off = reads->off;
+        mp->pos_off.assign(pos_off, pos_off + reads->total + 1);
+        if (pos_off[0] != 0) PHMM_THROW(PHMM_EINVAL, "pos_off[0] must be 0");
+        for (uint64_t i = 0; i < reads->total; i++) {
+            if (pos_off[i + 1] < pos_off[i]) PHMM_THROW(PHMM_EINVAL, "pos_off not monotone");
+            if (pos_off[i + 1] - pos_off[i] > PHMM_MAX_ACTIVE_NODES)
+                PHMM_THROW(PHMM_ECAPACITY, "a mapping position lists more than 400 nodes");
+        }
+        const uint64_t te = pos_off[reads->total];
+        if (te && !nodes) PHMM_THROW(PHMM_EINVAL, "NULL nodes");
+        mp->nodes.assign(nodes, nodes + te);
+        if (logp) mp->logp.assign(logp, logp + te);
+        else mp->logp.assign(te, 0.0);
+        *out = mp;
+    });
+    if (rc != PHMM_OK) delete mp;
+    return rc;
+}
+uint64_t phmm_mappings_total_positions(const phmm_mappings *mp) { return mp ? mp->total_pos : 0; }
+uint64_t phmm_mappings_total_entries(const phmm_mappings *mp) { return mp ? mp->nodes.size() : 0; }
+int phmm_mappings_export(const phmm_mappings *mp, uint64_t *pos_off, uint32_t *nodes, double *logp) {
+    return guarded([&] {
+        if (!mp) PHMM_THROW(PHMM_EINVAL, "NULL mappings");
+        if (pos_off) std::memcpy(pos_off, mp->pos_off.data(), mp->pos_off.size() * sizeof(uint64_t));
+        if (nodes) std::memcpy(nodes, mp->nodes.data(), mp->nodes.size() * sizeof(uint32_t));
+        if (logp) std::memcpy(logp, mp->logp.data(), mp->logp.size() * sizeof(double));
+    });
+}
+void phmm_mappings_destroy(phmm_mappings *mp) { delete mp; }
+
+}  // extern "C"

@@ -1,0 +1,773 @@
+// Dense forward / backward / posterior kernels for gfx950 (MI355X).
+//
+// What they compute (reference file:line, relative to the dbgphmm tree):
+//   forward  column: f_step = fm; fi; fmb; fib; fd(fd0 + n_max_gaps x fdt); fe
+//                    src/hmmv2/forward.rs:276-306, 337-558
+//   backward column: b_step = bd(bd0 + n_max_gaps x bdt); be; bm; bi; bib; bmb
+//                    src/hmmv2/backward.rs:216-261, 299-565
+//   posteriors:      to_emit_probs / to_state_probs / to_node_freqs
+//                    src/hmmv2/table.rs:500-505, src/hmmv2/freq.rs:230-255
+//
+// How (DESIGN.md sections 3-5):
+//   * HBM layout  T[group][pos][node][W]  (f64): the W reads of a read group are the
+//     fastest dimension, so a wave touches W consecutive doubles per node and every
+//     parent/child gather is a contiguous 8*W-byte row whatever the graph looks like.
+//   * scaled linear domain: a column is stored as value * 2^-E[pos] with a power-of-two
+//     (hence exact) rescale chosen from the previous column's maximum; log P is
+//     recovered as log(sum) + E*ln2.  No exp/log in the inner loop.
+//   * the silent Del chain (1 + n_max_gaps dependent sweeps per column in the
+//     reference) is folded into per-node "closure" lists built on the host
+//     (model.cpp), so one launch per read position has no intra-column dependency:
+//     launch `pos` writes m,i of column pos and d of column pos-1.
+//   * all reductions (column maxima, end sums, begin sums, node posteriors) are done
+//     in a fixed order: results are bit-reproducible run to run.
+//   * blockIdx -> node-range mapping is XCD-aware (blocks b and b+8 share an XCD/L2):
+//     each XCD owns one contiguous eighth of the node range, so closure gathers of
+//     neighbouring node blocks hit the same L2.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "phmm_internal.h"
+
+namespace phmm {
+
+static constexpr double LN2 = 0.693147180559945309417232121458;
+static constexpr int BLOCK = 256;
+
+struct DenseArgs {
+    int N, ng, Lc, nblk, npt;
+    // model
+    const uint8_t *emis;
+    const double *init, *dinit, *tdinit;
+    const uint32_t *fc_off;
+    const FwdEntry *fc;
+    const uint32_t *bc_off;
+    const BwdEntry *bc;
+    LinParams lp;
+    const double *logib;  // [Lc] forward InsBegin chain (log)
+    // read batch
+    const uint8_t *bases;  // [ng][Lc][W]
+    const int *len;        // [ng][W]
+    // forward tables
+    double *Fm, *Fi, *Fd;          // [ng][Lc][N][W]
+    int *FE;                       // [ng][Lc+1][W]
+    unsigned long long *cmaxF;     // [ng][Lc][W]
+    double *epart;                 // [ng][ecols][nblk8][W]
+    int eall;                      // 1: end sum for every column (debug tables)
+    double *logPf;                 // [ng][W]
+    double *logE;                  // [ng][Lc][W] per-column e (debug)
+    // backward tables
+    double *Bm, *Bi, *Bd;          // [ng][bcols][N][W]  (Bd may be null)
+    int bcols;                     // 2 (ping-pong) or Lc
+    int *BE;                       // [ng][Lc+1][W]
+    unsigned long long *cmaxB;     // [ng][Lc][W]
+    double *bpart;                 // [2][ng][nblk8][W][2]
+    double *logmbB, *logibB;       // [ng][Lc+1][W]
+    double *accg;                  // [ng][N]
+    int want_freq;
+    int nblk8;                     // nblk rounded up to a multiple of 8 (grid.x)
+};
+
+__device__ __forceinline__ int xcd_block(int b, int nblk8) {
+    // physical block b runs on XCD (b % 8); give each XCD a contiguous node range.
+    int per = nblk8 >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+// exponent e with v * 2^-e in [0.5, 1) for v > 0 (normal); 0 for v == 0
+__device__ __forceinline__ int exp_of_bits(unsigned long long bits) {
+    int be = (int)((bits >> 52) & 0x7ff);
+    if (bits == 0ull) return 0;
+    if (be == 0) return -1022;  // subnormal maximum: scale up as far as is safe
+    return be - 1022;
+}
+__device__ __forceinline__ double pow2(int e) {  // e in [-1022, 1023]
+    return __longlong_as_double((long long)(e + 1023) << 52);
+}
+
+// Reduce over all threads of the block that share r = tid % W.  Result valid for tid < W.
+template <int W, class Op>
+__device__ __forceinline__ double block_reduce_rows(double v, Op op, double *lds) {
+#pragma unroll
+    for (int off = W; off < 64; off <<= 1) v = op(v, __shfl_xor(v, off));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane < W) lds[wave * 64 + lane] = v;
+    __syncthreads();
+    double out = v;
+    if (threadIdx.x < W) {
+        out = lds[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; w++) out = op(out, lds[w * 64 + threadIdx.x]);
+    }
+    return out;
+}
+// Sum over the W lanes that share one node (contiguous lane group); valid in every lane.
+template <int W> __device__ __forceinline__ double lanes_sum(double v) {
+#pragma unroll
+    for (int off = 1; off < W; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+struct OpMax {
+    __device__ double operator()(double a, double b) const { return a > b ? a : b; }
+};
+struct OpAdd {
+    __device__ double operator()(double a, double b) const { return a + b; }
+};
+
+// ------------------------------------------------------------------ forward step
+// Launch `pos` (0..Lc): column pos of m,i for lanes with pos < len; d of column pos-1
+// for lanes with 1 <= pos <= len; the end sum of the last column for lanes with pos == len.
+template <int W>
+__global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int pos) {
+    __shared__ double lds[(BLOCK / 64) * 64];
+    const int g = blockIdx.y;
+    const int lb = xcd_block(blockIdx.x, a.nblk8);
+    constexpr int ROWS = BLOCK / W;
+    const int r = threadIdx.x % W;
+    const int row = threadIdx.x / W;
+    const int len = a.len[g * W + r];
+    const bool newcol = pos < len;
+    const bool have_prev = pos >= 1 && pos <= len;
+    const bool fin = have_prev && pos == len;
+    const LinParams &lp = a.lp;
+    const size_t NW = (size_t)a.N * W;
+
+    int Epos = 0;
+    double sc = 1.0, isc = 1.0, ibs = 0.0;
+    if (have_prev) {
+        const unsigned long long cm = a.cmaxF[((size_t)g * a.Lc + (pos - 1)) * W + r];
+        const int e = exp_of_bits(cm);
+        sc = pow2(-e);
+        isc = pow2(e);
+        Epos = a.FE[((size_t)g * (a.Lc + 1) + (pos - 1)) * W + r] + e;
+        // fib, forward.rs:541-545 (read-independent chain, log domain on the host)
+        ibs = exp(a.logib[pos - 1] - (double)Epos * LN2);
+    }
+    const uint8_t x = newcol ? a.bases[((size_t)g * a.Lc + pos) * W + r] : (uint8_t)0;
+
+    const double *pm = a.Fm + ((size_t)g * a.Lc + (pos > 0 ? pos - 1 : 0)) * NW;
+    const double *pi = a.Fi + ((size_t)g * a.Lc + (pos > 0 ? pos - 1 : 0)) * NW;
+    double *pd = a.Fd + ((size_t)g * a.Lc + (pos > 0 ? pos - 1 : 0)) * NW;
+    double *cm_ = a.Fm + ((size_t)g * a.Lc + (pos < a.Lc ? pos : 0)) * NW;
+    double *ci_ = a.Fi + ((size_t)g * a.Lc + (pos < a.Lc ? pos : 0)) * NW;
+
+    double vmax = 0.0, esum = 0.0;
+    const bool want_e = fin || (a.eall && have_prev);
+    if (lb < a.nblk) {
+        const int kbase = lb * (a.npt * ROWS) + row;
+        for (int j = 0; j < a.npt; j++) {
+            int k = kbase + j * ROWS;
+            if (W == 64) k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= a.N) break;
+            if (!(newcol || have_prev)) continue;
+            double mnew, inew = 0.0;
+            const double pe = a.emis[k] == x ? lp.p_match : lp.p_mismatch;
+            if (pos == 0) {
+                // f_init: mb = 1, everything else 0 (forward.rs:255-266)
+                mnew = pe * a.init[k] * lp.p_MM;
+            } else {
+                double m1 = 0.0, i1 = 0.0, dacc = 0.0, tacc = 0.0;
+                const uint32_t o0 = a.fc_off[k], o1 = a.fc_off[k + 1];
+                for (uint32_t q = o0; q < o1; q++) {
+                    const FwdEntry en = a.fc[q];
+                    const size_t ix = (size_t)en.node * W + r;
+                    const double vm = pm[ix] * sc, vi = pi[ix] * sc;
+                    const double gg = lp.p_MD * vm + lp.p_ID * vi;
+                    m1 += en.w1 * vm;
+                    i1 += en.w1 * vi;
+                    dacc += en.wD * gg;
+                    tacc += en.wT * gg;
+                }
+                const size_t ik = (size_t)k * W + r;
+                const double om = pm[ik] * sc, oi = pi[ik] * sc;
+                const double c = lp.p_ID * ibs;  // p_MD*mb + p_ID*ib with mb = 0 (fmb)
+                const double dprev = dacc + c * a.dinit[k];
+                const double td = tacc + c * a.tdinit[k];
+                pd[ik] = dprev * isc;  // stored in column pos-1's own exponent
+                mnew = pe * (lp.p_MM * m1 + lp.p_IM * i1 + lp.p_DM * td + a.init[k] * (lp.p_IM * ibs));
+                inew = lp.p_random * (lp.p_MI * om + lp.p_II * oi + lp.p_DI * dprev);
+                if (want_e) esum += om + oi + dprev;
+            }
+            if (newcol) {
+                const size_t ik = (size_t)k * W + r;
+                cm_[ik] = mnew;
+                ci_[ik] = inew;
+                vmax = fmax(vmax, fmax(mnew, inew));
+            }
+        }
+    }
+    // column maximum -> next launch's rescale.  The InsBegin value joins the maximum so
+    // that it can never overflow the scaled domain.
+    if (newcol && lb == 0 && row == 0 && pos >= 1) vmax = fmax(vmax, lp.p_random * lp.p_II * ibs);
+    if (newcol && lb == 0 && row == 0 && pos == 0) vmax = fmax(vmax, lp.p_random * lp.p_MI);
+    const double bm = block_reduce_rows<W>(vmax, OpMax(), lds);
+    if (threadIdx.x < W && newcol && lb < a.nblk)
+        atomicMax(&a.cmaxF[((size_t)g * a.Lc + pos) * W + r], (unsigned long long)__double_as_longlong(bm));
+    if (a.eall || __syncthreads_or(fin)) {
+        const double bs = block_reduce_rows<W>(esum, OpAdd(), lds);
+        if (threadIdx.x < W && want_e && lb < a.nblk) {
+            const size_t col = a.eall ? (size_t)(pos - 1) : 0;
+            const size_t ecols = a.eall ? (size_t)a.Lc : 1;
+            a.epart[(((size_t)g * ecols + col) * a.nblk8 + lb) * W + r] = bs;
+        }
+    }
+    if (lb == 0 && threadIdx.x < W && (newcol || have_prev))
+        a.FE[((size_t)g * (a.Lc + 1) + pos) * W + r] = Epos;
+}
+
+// log P(read) = ln(p_end * sum_k (m+i+d)) of the last column (fe, forward.rs:554-558)
+template <int W>
+__global__ void __launch_bounds__(BLOCK) fwd_finish(const DenseArgs a) {
+    __shared__ double lds[(BLOCK / 64) * 64];
+    const int g = blockIdx.x;
+    const int col = blockIdx.y;  // 0 unless eall
+    constexpr int ROWS = BLOCK / W;
+    const int r = threadIdx.x % W, row = threadIdx.x / W;
+    const int len = a.len[g * W + r];
+    const size_t ecols = a.eall ? (size_t)a.Lc : 1;
+    double s = 0.0;
+    const bool live = a.eall ? col < len : len > 0;
+    if (live)
+        for (int b = row; b < a.nblk; b += ROWS)
+            s += a.epart[(((size_t)g * ecols + col) * a.nblk8 + b) * W + r];
+    const double tot = block_reduce_rows<W>(s, OpAdd(), lds);
+    if (threadIdx.x < W && live) {
+        // the sum of column c was taken in the exponent of launch c+1
+        const int E = a.FE[((size_t)g * (a.Lc + 1) + (a.eall ? col + 1 : len)) * W + r];
+        const double lp = log(a.lp.p_end * tot) + (double)E * LN2;
+        if (a.eall) a.logE[((size_t)g * a.Lc + col) * W + r] = lp;
+        if (!a.eall || col == len - 1) a.logPf[g * W + r] = lp;
+    }
+}
+
+__device__ __forceinline__ double dev_logadd(double x, double y) {
+    const double hi = x >= y ? x : y, lo = x >= y ? y : x;
+    if (lo == -INFINITY) return hi;
+    return hi + log1p(exp(lo - hi));
+}
+
+// Begin-state chain of backward column p from the per-block partial sums of launch p
+// (bmb / bib, backward.rs:499-555), log domain.  Runs in block lb==0 of launch p-1 and
+// in bwd_finish for p == 0.
+template <int W>
+__device__ __forceinline__ void bwd_chain(const DenseArgs &a, int g, int p, double *lds) {
+    constexpr int ROWS = BLOCK / W;
+    const int r = threadIdx.x % W, row = threadIdx.x / W;
+    const int len = a.len[g * W + r];
+    const bool live = p < len;
+    double s1 = 0.0, s2 = 0.0;
+    if (live) {
+        const double *bp = a.bpart + ((size_t)(p & 1) * a.ng + g) * a.nblk8 * W * 2;
+        for (int b = row; b < a.nblk; b += ROWS) {
+            s1 += bp[((size_t)b * W + r) * 2 + 0];
+            s2 += bp[((size_t)b * W + r) * 2 + 1];
+        }
+    }
+    const double t1 = block_reduce_rows<W>(s1, OpAdd(), lds);
+    const double t2 = block_reduce_rows<W>(s2, OpAdd(), lds);
+    if (threadIdx.x < W && live) {
+        const size_t ix = ((size_t)g * (a.Lc + 1) + p) * W + r;
+        const double E = (double)a.BE[ix] * LN2;
+        const double ibn = (p + 1 < len) ? a.logibB[ix + W] : -INFINITY;  // b_init: ib = 0
+        const double lr = log(a.lp.p_random);
+        a.logmbB[ix] = dev_logadd(log(t1) + E, log(a.lp.p_MI) + lr + ibn);
+        a.logibB[ix] = dev_logadd(log(t2) + E, log(a.lp.p_II) + lr + ibn);
+    }
+}
+
+// ------------------------------------------------------------------ backward step
+// Launch `pos` (Lc-1 .. 0): column pos of m,i,d for lanes with pos < len, fused with the
+// posterior accumulation  S[pos] = F.tables[pos-1] (.) B.tables[pos] / P  (and the
+// j = L term F.tables[L-1] (.) B.init / P when pos == len-1).
+template <int W>
+__global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int pos) {
+    __shared__ double lds[(BLOCK / 64) * 64];
+    const int g = blockIdx.y;
+    const int lb = xcd_block(blockIdx.x, a.nblk8);
+    constexpr int ROWS = BLOCK / W;
+    const int r = threadIdx.x % W;
+    const int row = threadIdx.x / W;
+    const int len = a.len[g * W + r];
+    const bool live = pos < len;
+    const bool first = live && pos == len - 1;  // previous table is b_init (backward.rs:197-211)
+    const LinParams &lp = a.lp;
+    const size_t NW = (size_t)a.N * W;
+
+    if (lb == 0 && pos + 1 < a.Lc) bwd_chain<W>(a, g, pos + 1, lds);
+
+    int Epos = 0;
+    double sc = 1.0;
+    if (live && !first) {
+        const unsigned long long cm = a.cmaxB[((size_t)g * a.Lc + (pos + 1)) * W + r];
+        const int e = exp_of_bits(cm);
+        sc = pow2(-e);
+        Epos = a.BE[((size_t)g * (a.Lc + 1) + (pos + 1)) * W + r] + e;
+    }
+    const uint8_t x = live ? a.bases[((size_t)g * a.Lc + pos) * W + r] : (uint8_t)0;
+    const int cn = a.bcols == 2 ? ((pos + 1) & 1) : (pos + 1 < a.Lc ? pos + 1 : 0);
+    const int cc = a.bcols == 2 ? (pos & 1) : pos;
+    const double *nm = a.Bm + ((size_t)g * a.bcols + cn) * NW;
+    const double *ni = a.Bi + ((size_t)g * a.bcols + cn) * NW;
+    double *om = a.Bm + ((size_t)g * a.bcols + cc) * NW;
+    double *oi = a.Bi + ((size_t)g * a.bcols + cc) * NW;
+    double *od = a.Bd ? a.Bd + ((size_t)g * a.bcols + cc) * NW : nullptr;
+
+    // posterior weights  2^(FE+BE) / P
+    double wgt = 0.0, wgt2 = 0.0;
+    const double *fm = nullptr, *fi = nullptr, *fd = nullptr, *gm = nullptr, *gi = nullptr, *gd = nullptr;
+    if (a.want_freq && live) {
+        const double lpf = a.logPf[g * W + r];
+        if (lpf > -INFINITY) {
+            if (pos >= 1) {
+                const int fe = a.FE[((size_t)g * (a.Lc + 1) + (pos - 1)) * W + r];
+                wgt = exp((double)(fe + Epos) * LN2 - lpf);
+            }
+            if (first) {
+                const int fe = a.FE[((size_t)g * (a.Lc + 1) + pos) * W + r];
+                wgt2 = exp((double)fe * LN2 - lpf) * lp.p_end;
+            }
+        }
+    }
+    if (a.want_freq) {
+        const size_t cprev = ((size_t)g * a.Lc + (pos > 0 ? pos - 1 : 0)) * NW;
+        const size_t ccur = ((size_t)g * a.Lc + pos) * NW;
+        fm = a.Fm + cprev; fi = a.Fi + cprev; fd = a.Fd + cprev;
+        gm = a.Fm + ccur; gi = a.Fi + ccur; gd = a.Fd + ccur;
+    }
+
+    double vmax = 0.0, s1 = 0.0, s2 = 0.0;
+    if (lb < a.nblk) {
+        const int kbase = lb * (a.npt * ROWS) + row;
+        for (int j = 0; j < a.npt; j++) {
+            int v = kbase + j * ROWS;
+            if (W == 64) v = __builtin_amdgcn_readfirstlane(v);
+            if (v >= a.N) break;
+            double contrib = 0.0;
+            if (live) {
+                double a1 = 0.0, ad = 0.0, at = 0.0, qd = 0.0, qt = 0.0;
+                const uint32_t o0 = a.bc_off[v], o1 = a.bc_off[v + 1];
+                for (uint32_t q = o0; q < o1; q++) {
+                    const BwdEntry en = a.bc[q];
+                    const size_t ix = (size_t)en.node * W + r;
+                    const double mu = first ? lp.p_end : nm[ix] * sc;
+                    const double iu = first ? lp.p_end : ni[ix] * sc;
+                    const double h = ((uint8_t)en.emis == x ? lp.p_match : lp.p_mismatch) * mu;
+                    const double qq = lp.p_random * iu;
+                    a1 += en.c1 * h;
+                    ad += en.cAd * h;
+                    at += en.cAt * h;
+                    qd += en.cQd * qq;
+                    qt += en.cAd * qq;
+                }
+                const size_t iv = (size_t)v * W + r;
+                const double m0 = first ? lp.p_end : nm[iv] * sc;
+                const double q0 = lp.p_random * (first ? lp.p_end : ni[iv] * sc);
+                const double d = lp.p_DM * ad + lp.p_DI * (q0 + qd);
+                const double td = lp.p_DM * at + lp.p_DI * qt;
+                const double m = lp.p_MM * a1 + lp.p_MD * td + lp.p_MI * q0;
+                const double i = lp.p_IM * a1 + lp.p_ID * td + lp.p_II * q0;
+                om[iv] = m;
+                oi[iv] = i;
+                if (od) od[iv] = d;
+                vmax = fmax(vmax, fmax(m, i));
+                const double ev = a.emis[v] == x ? lp.p_match : lp.p_mismatch;
+                const double in = a.init[v];
+                s1 += in * (lp.p_MM * ev * m0 + lp.p_MD * d);
+                s2 += in * (lp.p_IM * ev * m0 + lp.p_ID * d);
+                if (wgt != 0.0) contrib = wgt * (fm[iv] * m + fi[iv] * i + fd[iv] * d);
+                if (wgt2 != 0.0) contrib += wgt2 * (gm[iv] + gi[iv] + gd[iv]);
+            }
+            if (a.want_freq) {
+                const double tot = lanes_sum<W>(contrib);
+                if (r == 0) a.accg[(size_t)g * a.N + v] += tot;
+            }
+        }
+    }
+    const double bmx = block_reduce_rows<W>(vmax, OpMax(), lds);
+    if (threadIdx.x < W && live && lb < a.nblk)
+        atomicMax(&a.cmaxB[((size_t)g * a.Lc + pos) * W + r], (unsigned long long)__double_as_longlong(bmx));
+    const double t1 = block_reduce_rows<W>(s1, OpAdd(), lds);
+    const double t2 = block_reduce_rows<W>(s2, OpAdd(), lds);
+    if (threadIdx.x < W && lb < a.nblk) {
+        double *bp = a.bpart + ((size_t)(pos & 1) * a.ng + g) * a.nblk8 * W * 2;
+        bp[((size_t)lb * W + r) * 2 + 0] = t1;
+        bp[((size_t)lb * W + r) * 2 + 1] = t2;
+    }
+    if (lb == 0 && threadIdx.x < W && live) a.BE[((size_t)g * (a.Lc + 1) + pos) * W + r] = Epos;
+}
+
+template <int W>
+__global__ void __launch_bounds__(BLOCK) bwd_finish(const DenseArgs a) {
+    __shared__ double lds[(BLOCK / 64) * 64];
+    bwd_chain<W>(a, blockIdx.x, 0, lds);
+}
+
+// node_freq[k] = sum over groups (fixed order) of accg[g][k]
+__global__ void __launch_bounds__(BLOCK) freq_reduce(const double *accg, int ng, int N, double *out, int accumulate) {
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= N) return;
+    double s = accumulate ? out[k] : 0.0;
+    for (int g = 0; g < ng; g++) s += accg[(size_t)g * N + k];
+    out[k] = s;
+}
+
+// debug: scaled linear table -> natural-log table in the caller's [L][N] layout (W == 1)
+__global__ void __launch_bounds__(BLOCK) to_log_tables(const double *T, const int *E, int Lc, int N, int L,
+                                                       double *out) {
+    const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= (size_t)L * N) return;
+    const int pos = (int)(idx / N);
+    const double v = T[idx];
+    out[idx] = v > 0.0 ? log(v) + (double)E[pos] * LN2 : -INFINITY;
+}
+
+// ------------------------------------------------------------------ host driver
+namespace {
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on;
+    explicit Timer(bool on_) : on(on_) {
+        if (on) {
+            HIP_CHECK(hipEventCreate(&a));
+            HIP_CHECK(hipEventCreate(&b));
+        }
+    }
+    ~Timer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    void start() {
+        if (on) HIP_CHECK(hipEventRecord(a, current_stream()));
+    }
+    double stop() {
+        if (!on) return 0.0;
+        HIP_CHECK(hipEventRecord(b, current_stream()));
+        HIP_CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        return ms;
+    }
+};
+
+template <int W>
+void launch_chunk(const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
+    hipStream_t s = current_stream();
+    dim3 grid(a.nblk8, a.ng), blk(BLOCK);
+    Timer tf(timing), tb(timing);
+    tf.start();
+    for (int pos = 0; pos <= a.Lc; pos++) hipLaunchKernelGGL(fwd_step<W>, grid, blk, 0, s, a, pos);
+    st.ms[0] += tf.stop();
+    st.launches[0] += (uint64_t)a.Lc + 1;
+    hipLaunchKernelGGL(fwd_finish<W>, dim3(a.ng, a.eall ? a.Lc : 1), blk, 0, s, a);
+    if (do_bwd) {
+        tb.start();
+        for (int pos = a.Lc - 1; pos >= 0; pos--) hipLaunchKernelGGL(bwd_step<W>, grid, blk, 0, s, a, pos);
+        st.ms[1] += tb.stop();
+        st.launches[1] += (uint64_t)a.Lc;
+        hipLaunchKernelGGL(bwd_finish<W>, dim3(a.ng), blk, 0, s, a);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_chunk_w(int W, const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
+    switch (W) {
+    case 1: launch_chunk<1>(a, do_bwd, st, timing); break;
+    case 2: launch_chunk<2>(a, do_bwd, st, timing); break;
+    case 4: launch_chunk<4>(a, do_bwd, st, timing); break;
+    case 8: launch_chunk<8>(a, do_bwd, st, timing); break;
+    case 16: launch_chunk<16>(a, do_bwd, st, timing); break;
+    case 32: launch_chunk<32>(a, do_bwd, st, timing); break;
+    case 64: launch_chunk<64>(a, do_bwd, st, timing); break;
+    default: PHMM_THROW(PHMM_EINTERNAL, "bad read-group width");
+    }
+}
+
+// largest W in {64,..,1} whose padding waste is <= 1/16 of the lanes
+int choose_width(uint64_t R) {
+    for (int W = 64; W >= 2; W >>= 1) {
+        uint64_t padded = (R + W - 1) / W * W;
+        if ((padded - R) * 16 <= padded) return W;
+    }
+    return 1;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// carve sub-buffers out of one allocation
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base((char *)b) {}
+    template <class T> T *take(size_t n) {
+        off = align_up(off, 256);
+        T *p = base ? (T *)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct Plan {
+    int W, ng_total, npt, nblk, nblk8;
+    std::vector<uint32_t> order;  // reads sorted by length, descending
+};
+
+Plan make_plan(const phmm_model *m, const phmm_reads *reads, int forced_w) {
+    Plan p;
+    const uint64_t R = reads->R;
+    p.order.resize(R);
+    std::iota(p.order.begin(), p.order.end(), 0u);
+    std::stable_sort(p.order.begin(), p.order.end(), [&](uint32_t x, uint32_t y) {
+        return reads->off[x + 1] - reads->off[x] > reads->off[y + 1] - reads->off[y];
+    });
+    p.W = forced_w > 0 ? forced_w : choose_width(R);
+    p.ng_total = (int)((R + p.W - 1) / p.W);
+    const int rows = BLOCK / p.W;
+    // nodes per thread: keep the per-column partial count (blocks) <= ~2048
+    int npt = 4;
+    while ((int64_t)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows)) > 2048 && npt < 64) npt *= 2;
+    p.npt = npt;
+    p.nblk = (int)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows));
+    p.nblk8 = (p.nblk + 7) / 8 * 8;
+    return p;
+}
+
+struct ChunkBuffers {
+    DenseArgs a;
+    size_t table_bytes, misc_bytes;
+};
+
+// lay out one chunk (ngc groups, Lc columns); pass null bases to measure
+void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &tb, size_t &mb) {
+    const size_t NW = (size_t)a.N * W;
+    Carver t(tables), s(misc);
+    a.Fm = t.take<double>((size_t)a.ng * a.Lc * NW);
+    a.Fi = t.take<double>((size_t)a.ng * a.Lc * NW);
+    a.Fd = t.take<double>((size_t)a.ng * a.Lc * NW);
+    a.bcols = full_b ? a.Lc : 2;
+    a.Bm = t.take<double>((size_t)a.ng * a.bcols * NW);
+    a.Bi = t.take<double>((size_t)a.ng * a.bcols * NW);
+    a.Bd = full_b ? t.take<double>((size_t)a.ng * a.bcols * NW) : nullptr;
+    tb = t.off;
+    a.bases = s.take<uint8_t>((size_t)a.ng * a.Lc * W);
+    a.len = s.take<int>((size_t)a.ng * W);
+    a.FE = s.take<int>((size_t)a.ng * (a.Lc + 1) * W);
+    a.BE = s.take<int>((size_t)a.ng * (a.Lc + 1) * W);
+    a.cmaxF = s.take<unsigned long long>((size_t)a.ng * a.Lc * W);
+    a.cmaxB = s.take<unsigned long long>((size_t)a.ng * a.Lc * W);
+    a.epart = s.take<double>((size_t)a.ng * (a.eall ? a.Lc : 1) * a.nblk8 * W);
+    a.logPf = s.take<double>((size_t)a.ng * W);
+    a.logE = s.take<double>(a.eall ? (size_t)a.ng * a.Lc * W : 1);
+    a.bpart = s.take<double>((size_t)2 * a.ng * a.nblk8 * W * 2);
+    a.logmbB = s.take<double>((size_t)a.ng * (a.Lc + 1) * W);
+    a.logibB = s.take<double>((size_t)a.ng * (a.Lc + 1) * W);
+    a.accg = s.take<double>((size_t)a.ng * a.N);
+    a.logib = s.take<double>((size_t)a.Lc + 1);
+    mb = s.off;
+}
+
+void fill_model_args(DenseArgs &a, const phmm_model *m) {
+    const ModelDev &d = m->dev;
+    a.N = (int)m->N;
+    a.emis = d.emis.as<uint8_t>();
+    a.init = d.init.as<double>();
+    a.dinit = d.dinit.as<double>();
+    a.tdinit = d.tdinit.as<double>();
+    a.fc_off = d.fc_off.as<uint32_t>();
+    a.fc = d.fc_ent.as<FwdEntry>();
+    a.bc_off = d.bc_off.as<uint32_t>();
+    a.bc = d.bc_ent.as<BwdEntry>();
+    a.lp = m->lin;
+}
+
+// forward InsBegin chain in the log domain: ib_0 = p_r*(p_MI*1 + p_II*0); ib_i = p_r*p_II*ib_{i-1}
+// (fib, forward.rs:541-545 with f_init / fmb, forward.rs:255-266, 531-533)
+void host_logib(const phmm_model *m, size_t n, std::vector<double> &out) {
+    out.resize(n + 1);
+    const phmm_params &p = m->params;
+    double ib = p.p_random + p.p_MI;
+    for (size_t i = 0; i <= n; i++) {
+        out[i] = ib;
+        ib = p.p_random + p.p_II + ib;
+    }
+}
+
+}  // namespace
+
+void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, uint64_t R,
+                    const Plan &plan, bool full_b, bool eall, bool want_b, bool want_freq,
+                    double *out_lf, double *out_lb, double *out_nf, DenseArgs *dbg_args) {
+    hipStream_t s = current_stream();
+    CallStats &st = stats();
+    st = CallStats();
+    const int W = plan.W;
+    const size_t NW = (size_t)m->N * W;
+    const uint64_t limit = workspace_limit();
+
+    DenseArgs base{};
+    fill_model_args(base, m);
+    base.nblk = plan.nblk;
+    base.nblk8 = plan.nblk8;
+    base.npt = plan.npt;
+    base.eall = eall ? 1 : 0;
+    base.want_freq = want_freq ? 1 : 0;
+
+    // per-read results gathered on the host in the caller's order
+    std::vector<double> lf(R), lb(want_b ? R : 0);
+    DevBuf &nf_dev = m->ws_out;
+    if (want_freq) {
+        nf_dev.reserve(sizeof(double) * m->N);
+        HIP_CHECK(hipMemsetAsync(nf_dev.p, 0, sizeof(double) * m->N, s));
+    }
+
+    int g0 = 0;
+    bool first_chunk = true;
+    while (g0 < plan.ng_total) {
+        // chunk = as many consecutive groups as fit; Lc = longest read of the chunk
+        const uint32_t r0 = plan.order[(size_t)g0 * W];
+        const int Lc = (int)(off[r0 + 1] - off[r0]);
+        const size_t per_group = (size_t)Lc * NW * 24 + (size_t)(full_b ? Lc * 3 : 4) * NW * 8;
+        int ngc = (int)std::min<uint64_t>(plan.ng_total - g0, std::max<uint64_t>(1, limit / std::max<size_t>(per_group, 1)));
+        DenseArgs a = base;
+        a.ng = ngc;
+        a.Lc = Lc;
+        size_t tb = 0, mb = 0;
+        layout(a, W, full_b, nullptr, nullptr, tb, mb);
+        m->ws_tables.reserve(tb);
+        m->ws_misc.reserve(mb);
+        layout(a, W, full_b, m->ws_tables.p, m->ws_misc.p, tb, mb);
+        HIP_CHECK(hipMemsetAsync(m->ws_misc.p, 0, mb, s));
+
+        // host staging: transposed bases, lengths, logib
+        std::vector<uint8_t> hb((size_t)ngc * Lc * W, 0xff);
+        std::vector<int> hl((size_t)ngc * W, 0);
+        uint64_t cells = 0;
+        for (int g = 0; g < ngc; g++)
+            for (int r = 0; r < W; r++) {
+                const size_t slot = (size_t)(g0 + g) * W + r;
+                if (slot >= R) continue;
+                const uint32_t rd = plan.order[slot];
+                const uint64_t len = off[rd + 1] - off[rd];
+                hl[(size_t)g * W + r] = (int)len;
+                cells += len * m->N;
+                for (uint64_t i = 0; i < len; i++) hb[((size_t)g * Lc + i) * W + r] = bases[off[rd] + i];
+            }
+        std::vector<double> hib;
+        host_logib(m, (size_t)Lc, hib);
+        HIP_CHECK(hipMemcpyAsync((void *)a.bases, hb.data(), hb.size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync((void *)a.len, hl.data(), hl.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync((void *)a.logib, hib.data(), hib.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));  // staging vectors may now die; timed region excludes upload
+
+        launch_chunk_w(W, a, want_b || want_freq, st, timing_enabled());
+        st.cells[0] += cells;
+        if (want_b || want_freq) st.cells[1] += cells;
+
+        if (want_freq)
+            hipLaunchKernelGGL(freq_reduce, dim3((m->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, a.accg, ngc,
+                               (int)m->N, nf_dev.as<double>(), first_chunk ? 0 : 1);
+        // per-read totals back to caller order
+        std::vector<double> tlf((size_t)ngc * W), tlb;
+        HIP_CHECK(hipMemcpyAsync(tlf.data(), a.logPf, tlf.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        std::vector<double> tmb;
+        if (want_b) {
+            tmb.resize((size_t)ngc * (Lc + 1) * W);
+            HIP_CHECK(hipMemcpyAsync(tmb.data(), a.logmbB, tmb.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (int g = 0; g < ngc; g++)
+            for (int r = 0; r < W; r++) {
+                const size_t slot = (size_t)(g0 + g) * W + r;
+                if (slot >= R) continue;
+                const uint32_t rd = plan.order[slot];
+                lf[rd] = tlf[(size_t)g * W + r];
+                if (want_b) lb[rd] = tmb[((size_t)g * (Lc + 1) + 0) * W + r];
+            }
+        if (dbg_args) *dbg_args = a;
+        g0 += ngc;
+        first_chunk = false;
+    }
+    // outputs: host vectors -> caller (host or device)
+    auto put = [&](double *dst, const std::vector<double> &src) {
+        if (!dst) return;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeDevice) {
+            HIP_CHECK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        } else {
+            (void)hipGetLastError();
+            std::memcpy(dst, src.data(), src.size() * sizeof(double));
+        }
+    };
+    put(out_lf, lf);
+    if (want_b) put(out_lb, lb);
+    if (want_freq && out_nf) copy_out(out_nf, nf_dev.p, sizeof(double) * m->N);
+}
+
+void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb, double *out_nf) {
+    Plan plan = make_plan(m, reads, 0);
+    run_dense_impl(m, reads->bases.data(), reads->off.data(), reads->R, plan, false, false, out_lb != nullptr,
+                   out_nf != nullptr, out_lf, out_lb, out_nf, nullptr);
+}
+
+void dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i, double *f_d,
+                  double *f_scal, double *b_m, double *b_i, double *b_d, double *b_scal) {
+    hipStream_t s = current_stream();
+    phmm_reads one;
+    one.R = 1;
+    one.total = len;
+    one.bases.assign(read, read + len);
+    one.off = {0, len};
+    one.max_len = len;
+    Plan plan = make_plan(m, &one, 1);
+    const bool want_b = b_m || b_i || b_d || b_scal;
+    DenseArgs a{};
+    double lf = 0, lb = 0;
+    run_dense_impl(m, one.bases.data(), one.off.data(), 1, plan, true, true, want_b, false, &lf, want_b ? &lb : nullptr,
+                   nullptr, &a);
+    const int L = (int)len, N = (int)m->N;
+    const size_t n = (size_t)L * N;
+    DevBuf tmp;
+    tmp.reserve(n * sizeof(double));
+    auto conv = [&](const double *T, const int *E, double *dst) {
+        if (!dst) return;
+        hipLaunchKernelGGL(to_log_tables, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, T, E, a.Lc, N, L,
+                           tmp.as<double>());
+        HIP_CHECK(hipMemcpyAsync(dst, tmp.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    };
+    conv(a.Fm, a.FE, f_m);
+    conv(a.Fi, a.FE, f_i);
+    conv(a.Fd, a.FE, f_d);
+    if (f_scal) {
+        std::vector<double> e((size_t)L), hib;
+        HIP_CHECK(hipMemcpy(e.data(), a.logE, sizeof(double) * L, hipMemcpyDeviceToHost));
+        host_logib(m, (size_t)L, hib);
+        for (int i = 0; i < L; i++) {
+            f_scal[3 * i + 0] = -INFINITY;  // fmb: mb = 0 (forward.rs:531-533)
+            f_scal[3 * i + 1] = hib[i];
+            f_scal[3 * i + 2] = e[i];
+        }
+    }
+    if (want_b) {
+        conv(a.Bm, a.BE, b_m);
+        conv(a.Bi, a.BE, b_i);
+        conv(a.Bd, a.BE, b_d);
+        if (b_scal) {
+            std::vector<double> mbv((size_t)L + 1), ibv((size_t)L + 1);
+            HIP_CHECK(hipMemcpy(mbv.data(), a.logmbB, sizeof(double) * (L + 1), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(ibv.data(), a.logibB, sizeof(double) * (L + 1), hipMemcpyDeviceToHost));
+            for (int i = 0; i < L; i++) {
+                b_scal[3 * i + 0] = mbv[i];
+                b_scal[3 * i + 1] = ibv[i];
+                b_scal[3 * i + 2] = -INFINITY;  // be (backward.rs:563-565)
+            }
+        }
+    }
+}
+
+}  // namespace phmm

@@ -1,0 +1,158 @@
+// Internal declarations shared by the host side and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/phmm_amd.h"
+
+namespace phmm {
+
+// ---------------------------------------------------------------- errors
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+struct Error {
+    int code;
+    std::string msg;
+};
+#define PHMM_THROW(code, msg) throw ::phmm::Error{(code), (msg)}
+#define HIP_CHECK(expr)                                                                      \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            PHMM_THROW(_e == hipErrorOutOfMemory ? PHMM_ENOMEM : PHMM_ENODEVICE,             \
+                       std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+    } while (0)
+
+hipStream_t current_stream();
+uint64_t workspace_limit();
+
+// ---------------------------------------------------------------- device buffers
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // grow-only
+    void reserve(size_t n) {
+        if (n <= bytes) return;
+        release();
+        HIP_CHECK(hipMalloc(&p, n ? n : 1));
+        bytes = n;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+    void upload(const void *src, size_t n) {
+        reserve(n);
+        if (n) HIP_CHECK(hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, current_stream()));
+    }
+};
+// copy device -> (host or device) destination
+void copy_out(void *dst, const void *src_dev, size_t bytes);
+
+// ---------------------------------------------------------------- linear-domain parameters
+// The kernels run in the (scaled) linear probability domain; see DESIGN.md.
+struct LinParams {
+    double p_mismatch, p_match, p_random, p_end;
+    double p_MM, p_IM, p_DM, p_MI, p_II, p_DI, p_MD, p_ID, p_DD;
+    int n_max_gaps;
+};
+
+// ancestor closure entry (forward): node a reaches k in `hop` edges with path weight w.
+//   w1 = w if hop==1 (direct parent: p_MM/p_IM terms)
+//   wD = pDD^(hop-1) w  for hop <= G+1   -> d[k]      = sum wD * g[a] + c*dinit[k]
+//   wT = pDD^(hop-2) w  for 2<=hop<=G+2  -> (T d)[k]  = sum wT * g[a] + c*tdinit[k]
+// with g[a] = p_MD m[a] + p_ID i[a]   (forward.rs:423-524 unrolled; DESIGN.md "Del closure")
+struct FwdEntry {
+    uint32_t node;
+    uint32_t pad;
+    double w1, wD, wT;
+};
+// descendant closure entry (backward): v reaches u in `hop` edges with path weight w.
+//   c1  = w if hop==1
+//   cAd = pDD^(hop-1) w for hop <= G+1 ; cAt = pDD^(hop-2) w for 2<=hop<=G+2
+//   cQd = pDD^hop w     for hop <= G      (cQt == cAd)
+// (backward.rs:299-483 unrolled)
+struct BwdEntry {
+    uint32_t node;
+    uint32_t emis;
+    double c1, cAd, cAt, cQd;
+};
+
+struct ModelDev {
+    uint32_t N = 0, E = 0;
+    DevBuf emis;             // u8[N]
+    DevBuf init;             // f64[N] linear
+    DevBuf dinit, tdinit;    // f64[N]
+    DevBuf fc_off, fc_ent;   // u32[N+1], FwdEntry[]
+    DevBuf bc_off, bc_ent;   // u32[N+1], BwdEntry[]
+    // parent / child CSR in linear domain for the sparse kernels
+    DevBuf par_off, par_node, par_w;  // u32[N+1], u32[E], f64[E]
+    DevBuf chi_off, chi_node, chi_w;
+    DevBuf par_edge, chi_edge;        // u32[E] edge ids (candidate batches index trans by edge)
+};
+
+}  // namespace phmm
+
+struct phmm_model {
+    uint32_t N = 0, E = 0;
+    phmm_params params{};
+    phmm::LinParams lin{};
+    std::vector<uint8_t> emission;
+    std::vector<double> init_logp, trans_logp;
+    std::vector<uint32_t> esrc, edst;
+    // host CSR (petgraph order: newest edge first)
+    std::vector<uint32_t> par_off, par_node, par_edge, chi_off, chi_node, chi_edge;
+    std::vector<double> logib;  // forward InsBegin chain, log domain (forward.rs:541-545)
+    phmm::ModelDev dev;
+    // grow-only workspaces
+    phmm::DevBuf ws_tables, ws_misc, ws_out;
+};
+
+struct phmm_reads {
+    uint64_t R = 0, total = 0;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> off;
+    uint64_t max_len = 0;
+};
+
+struct phmm_mappings {
+    uint64_t R = 0, total_pos = 0;
+    std::vector<uint64_t> read_off;  // [R+1] position offsets per read
+    std::vector<uint64_t> pos_off;   // [total_pos+1]
+    std::vector<uint32_t> nodes;
+    std::vector<double> logp;
+};
+
+namespace phmm {
+
+struct CallStats {
+    double ms[4] = {0, 0, 0, 0};
+    uint64_t launches[4] = {0, 0, 0, 0};
+    uint64_t cells[4] = {0, 0, 0, 0};
+};
+CallStats &stats();
+bool timing_enabled();
+
+void model_build_host(phmm_model *m);    // CSR + logib
+void model_upload(phmm_model *m);        // closures + device arrays
+
+// dense driver (dense.hip)
+void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb,
+               double *out_nf);
+void dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i,
+                  double *f_d, double *f_scal, double *b_m, double *b_i, double *b_d,
+                  double *b_scal);
+
+}  // namespace phmm

@@ -1,0 +1,174 @@
+/*
+ * phmm_amd.h -- C ABI of the MI355X-native profile-HMM read-likelihood path.
+ *
+ * Drop-in boundary for dbgphmm's `src/hmmv2`: the reference has no FFI layer; its
+ * boundary is the set of `impl PHMMModel` methods.  Each entry point below names the
+ * reference method it replaces (file:line relative to the dbgphmm source tree).  A Rust
+ * shim flattens its petgraph `PHMMModel` into these arrays and calls through
+ * `extern "C"` (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all probabilities cross the boundary as f64
+ *    natural-log values (the reference's `Prob`), node ids as u32 (`NodeIndex`),
+ *    bases as ASCII u8.
+ *  - input pointers are HOST pointers.  Output pointers may be host OR device
+ *    pointers (detected with hipPointerGetAttributes): device outputs let the caller
+ *    all-reduce `node_freq` / totals over RCCL without a host round trip.
+ *  - every function returns 0 on success or a negative PHMM_E* code;
+ *    phmm_last_error() returns the message (thread-local).  Nothing unwinds across
+ *    the ABI.  Where the reference panics (empty read, capacity overflow) the call
+ *    fails with PHMM_EINVAL / PHMM_ECAPACITY.
+ *  - handles own their device memory; destroy them explicitly.  Calls on one handle
+ *    are not re-entrant; the natural cut is one call per read set (all reads x all
+ *    candidates), replacing the rayon `par_iter` loops of the reference.
+ */
+#ifndef PHMM_AMD_H
+#define PHMM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHMM_OK 0
+#define PHMM_EINVAL (-1)    /* bad argument (reference: assert!/panic!) */
+#define PHMM_ENODEVICE (-2) /* no usable MI355X / HIP runtime error */
+#define PHMM_ENOMEM (-3)    /* device or host allocation failed */
+#define PHMM_ECAPACITY (-4) /* >400 active nodes (reference: ArrayVec panic, table.rs:22) */
+#define PHMM_EINTERNAL (-5)
+
+#define PHMM_MAX_ACTIVE_NODES 400 /* src/hmmv2/table.rs:22 */
+#define PHMM_MAX_GAPS 6           /* supported upper bound of n_max_gaps (reference default 4) */
+
+/* PHMMParams, src/hmmv2/params.rs:16-66.  p_* are natural-log probabilities. */
+typedef struct phmm_params {
+    double p_mismatch, p_match, p_random, p_gap_open, p_gap_ext, p_end;
+    double p_MM, p_IM, p_DM, p_MI, p_II, p_DI, p_MD, p_ID, p_DD;
+    int64_t n_active_nodes;
+    double active_node_max_ratio;
+    int64_t n_warmup;
+    int64_t warmup_threshold;
+    int64_t n_max_gaps;
+} phmm_params;
+
+typedef struct phmm_model phmm_model;       /* PHMMModel<N,E>, src/hmmv2/common.rs:61-64 */
+typedef struct phmm_reads phmm_reads;       /* ReadCollection<S>, src/common/collection.rs:38-83 */
+typedef struct phmm_mappings phmm_mappings; /* Mappings, src/hmmv2/hint.rs:150-152 */
+
+/* thread-local message of the last failing call */
+const char *phmm_last_error(void);
+/* "dbgphmm_amd <version> gfx950" */
+const char *phmm_version(void);
+/* number of visible HIP devices (0 without a GPU); does not initialise a context */
+int phmm_device_count(void);
+/* select the device for this thread's subsequent calls (one process per GPU: LOCAL_RANK) */
+int phmm_set_device(int device);
+/* run subsequent work of this thread on the given hipStream_t (NULL = default stream) */
+int phmm_set_stream(void *hip_stream);
+/* upper bound (bytes) for the DP-table workspace of one call; 0 = 80% of free HBM */
+int phmm_set_workspace_limit(uint64_t bytes);
+
+/* PHMMParams::new / uniform, params.rs:73-125 (arguments are LINEAR probabilities) */
+int phmm_params_new(double p_mismatch, double p_gap_open, double p_gap_ext, double p_end,
+                    int64_t n_active_nodes, int64_t n_warmup, phmm_params *out);
+int phmm_params_uniform(double p, phmm_params *out);
+
+/* ---- model ------------------------------------------------------------------
+ * Replaces SeqGraph::to_phmm's output (src/graph/seq_graph.rs:213-223): a PModel
+ * flattened to arrays.  Edges in petgraph insertion order.  The topology stays on the
+ * device; phmm_model_set_probs swaps init/trans for the next candidate copy-number
+ * vector (what `dbg.clone(); set_copy_nums; to_phmm` does per candidate,
+ * src/multi_dbg/posterior.rs:483-501). */
+int phmm_model_create(uint32_t n_nodes, uint32_t n_edges, const uint8_t *emission,
+                      const double *init_logp, const uint32_t *edge_src,
+                      const uint32_t *edge_dst, const double *trans_logp,
+                      const phmm_params *params, phmm_model **out);
+int phmm_model_set_probs(phmm_model *m, const double *init_logp, const double *trans_logp);
+int phmm_model_set_params(phmm_model *m, const phmm_params *params);
+uint32_t phmm_model_n_nodes(const phmm_model *m);
+uint32_t phmm_model_n_edges(const phmm_model *m);
+void phmm_model_destroy(phmm_model *m);
+
+/* ---- reads ------------------------------------------------------------------
+ * bases: concatenated reads; offsets[R+1].  Empty reads are rejected (the reference
+ * panics in last_table(), table.rs:388). */
+int phmm_reads_create(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                      phmm_reads **out);
+uint64_t phmm_reads_count(const phmm_reads *r);
+uint64_t phmm_reads_total_bases(const phmm_reads *r);
+void phmm_reads_destroy(phmm_reads *r);
+
+/* ---- dense forward + backward + posteriors ----------------------------------
+ * PHMMModel::run over a read set (src/hmmv2/freq.rs:42-46) followed by
+ * PHMMOutput::{to_full_prob_forward, to_full_prob_backward, to_node_freqs}
+ * (table.rs:482-494; freq.rs:245-255), i.e. PHMMModel::to_node_freqs /
+ * to_full_prob_parallel (freq.rs:89-119) in one call.
+ *   out_logp_forward[R]  = ln P(read) from the last forward table's `e`
+ *   out_logp_backward[R] = ln P(read) from the first backward table's `mb`   (may be NULL)
+ *   out_node_freq[N]     = sum over reads of node usage posteriors          (may be NULL)
+ * Any output may be a device pointer. */
+int phmm_run_dense(phmm_model *m, const phmm_reads *reads, double *out_logp_forward,
+                   double *out_logp_backward, double *out_node_freq);
+
+/* Dense tables of ONE read for parity tests / `inspect`-style tools:
+ * PHMMModel::forward / backward (forward.rs:24-45; backward.rs:24-53).
+ * f_m/f_i/f_d: [L][N] natural-log values of F.tables[i]; f_scal: [L][3] = mb, ib, e.
+ * b_*: the same for B.tables[i].  Any pointer may be NULL.  Host pointers. */
+int phmm_dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m,
+                      double *f_i, double *f_d, double *f_scal, double *b_m, double *b_i,
+                      double *b_d, double *b_scal);
+
+/* ---- mappings (hints) ---------------------------------------------------------
+ * Mappings (hint.rs:27-30,150-152) as a 3-level CSR over the reads of `reads`:
+ * pos_off[total_bases+1] indexes nodes[]/logp[] for every read position in read order. */
+int phmm_mappings_create(const phmm_reads *reads, const uint64_t *pos_off,
+                         const uint32_t *nodes, const double *logp, phmm_mappings **out);
+uint64_t phmm_mappings_total_positions(const phmm_mappings *mp);
+uint64_t phmm_mappings_total_entries(const phmm_mappings *mp);
+int phmm_mappings_export(const phmm_mappings *mp, uint64_t *pos_off, uint32_t *nodes,
+                         double *logp);
+/* Mappings::to_node_freqs, hint.rs:161-171 */
+int phmm_mappings_node_freqs(const phmm_mappings *mp, uint32_t n_nodes, double *out_freq);
+void phmm_mappings_destroy(phmm_mappings *mp);
+
+/* ---- read-set likelihood ------------------------------------------------------
+ * PHMMModel::to_full_prob_reads (freq.rs:175-192): per read
+ * forward_with_mapping_score_only (forward.rs:79-89) when mappings != NULL, else
+ * forward_sparse_score_only(use_max_ratio) (forward.rs:158-206).
+ *   out_logp[R] per-read ln P; out_total = their sum (rayon `.product()`).
+ * Either may be NULL / a device pointer. */
+int phmm_full_prob_reads(phmm_model *m, const phmm_reads *reads,
+                         const phmm_mappings *mappings, int use_max_ratio,
+                         double *out_logp, double *out_total);
+
+/* Candidate-batched form of the loop in sample_posterior_once
+ * (src/multi_dbg/posterior.rs:483-515): C candidate (init, trans) vectors on one
+ * topology, all reads, hinted forward.  init_logp [C][N], trans_logp [C][E] host
+ * pointers; out_logp [C][R] (may be NULL), out_total [C]. */
+int phmm_full_prob_reads_candidates(phmm_model *m, const phmm_reads *reads,
+                                    const phmm_mappings *mappings, uint32_t n_candidates,
+                                    const double *init_logp, const double *trans_logp,
+                                    double *out_logp, double *out_total);
+
+/* PHMMModel::generate_mappings (hint.rs:193-220): run_with_mapping when `mappings`
+ * is given else run_sparse_adaptive(use_max_ratio); then to_mapping_by_score_ratio /
+ * to_mapping.  out_node_freq[N] (may be NULL) = Mappings::to_node_freqs. */
+int phmm_generate_mappings(phmm_model *m, const phmm_reads *reads,
+                           const phmm_mappings *mappings, int use_max_ratio,
+                           phmm_mappings **out, double *out_node_freq);
+
+/* ---- instrumentation ------------------------------------------------------------
+ * Device time (ms, HIP events on the call's stream) and launch count of the dominant
+ * kernel class in the most recent call of this thread, plus the algorithmic cell
+ * count it processed (bench.py's roofline block).  which: 0 = dense forward step,
+ * 1 = dense backward+posterior step, 2 = hinted/sparse forward, 3 = sparse backward. */
+int phmm_last_call_stats(int which, double *out_ms, uint64_t *out_launches,
+                         uint64_t *out_cells);
+int phmm_enable_timing(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHMM_AMD_H */

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The HIP extension; fails loudly if it is not built or no GPU is visible."""
+    from dbgphmm_amd import _ffi
+    L = _ffi.lib()
+    assert L.phmm_device_count() > 0, "no HIP device visible: -m gpu tests need an MI355X"
+    return L

@@ -1,0 +1,148 @@
+"""GPU parity: dense forward / backward / posteriors through the C ABI vs the oracle and
+the reference's own known-answer values (tests/golden/kat_hmmv2.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import dbgphmm_amd as D
+from helpers import finite_close, small_dbg_model
+
+pytestmark = pytest.mark.gpu
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_hmmv2.json")))
+# |delta ln P| per read: BASELINE.json's bar is 1e-6; the scaled-f64 path is far inside it
+TOL_LOGP = 1e-9
+TOL_TABLE = 1e-9   # per table entry, log space, where finite (tests/hmm.rs:69-70)
+TOL_FREQ = 1e-9
+
+
+def test_forward_kat_zero_error(gpu_lib):
+    phmm = D.PHMMModel(D.mock_linear().to_phmm(D.PHMMParams.zero_error()))
+    r = phmm.forward(b"CGATC")
+    k = KAT["forward_zero_error"]
+    assert abs(r.m[2][5] - k["t2_m5"]) < 1e-5
+    assert abs(r.m[3][6] - k["t3_m6"]) < 1e-5
+    assert abs(r.m[4][7] - k["t4_m7"]) < 1e-5
+    assert abs(r.e[4] - k["t4_e"]) < 1e-5
+    assert np.all(np.isneginf(r.i)) and np.all(np.isneginf(r.d))
+    assert np.isneginf(phmm.forward(b"CGATT").e[4])
+
+
+def test_forward_backward_kat_high_error(gpu_lib):
+    phmm = D.PHMMModel(D.mock_linear().to_phmm(D.PHMMParams.high_error()))
+    k = KAT["high_error"]
+    r = phmm.forward(b"CGATC")
+    assert abs(r.e[4] - k["fwd_CGATC_e"]) < 1e-5
+    assert abs(r.m[4][7] - k["fwd_CGATC_t4_m7"]) < 1e-5
+    r2 = phmm.forward(b"CGATT")
+    assert abs(r2.e[4] - k["fwd_CGATT_e"]) < 1e-5
+    assert abs(r2.e[3] - r.e[3]) < 1e-5
+    b = phmm.backward(b"CGATC")
+    assert abs(b.m[0][2] - k["bwd_CGATC_t0_m2"]) < 1e-5
+    assert abs(b.mb[0] - k["bwd_CGATC_mb"]) < 1e-5
+    assert abs(phmm.backward(b"CGATT").mb[0] - k["bwd_CGATT_mb"]) < 1e-5
+
+
+def test_backward_kat_zero_error(gpu_lib):
+    phmm = D.PHMMModel(D.mock_linear().to_phmm(D.PHMMParams.zero_error()))
+    b = phmm.backward(b"CGATC")
+    k = KAT["backward_zero_error"]
+    assert abs(b.mb[0] - k["t0_mb"]) < 1e-5
+    for (t, n, v) in k["m"]:
+        assert abs(b.m[t][n] - v) < 1e-5
+    assert np.isneginf(phmm.backward(b"CGATT").mb[0])
+
+
+def test_node_freq_kat(gpu_lib):
+    phmm = D.PHMMModel(D.mock_linear().to_phmm(D.PHMMParams.zero_error()))
+    o = phmm.run(b"CGATC")
+    assert abs(o.to_full_prob_forward() - o.to_full_prob_backward()) < 1e-7
+    nf = o.to_node_freqs()
+    assert np.allclose(nf, [0, 0, 0, 1, 1, 1, 1, 1, 0, 0], atol=1e-5)
+    phmm = D.PHMMModel(D.mock_linear().to_phmm(D.PHMMParams.default()))
+    nf = phmm.run(b"ATTCGTCGT").to_node_freqs()  # one deletion: every node used once
+    assert np.allclose(nf, 1.0, atol=0.01)
+
+
+@pytest.mark.parametrize("case", ["linear_high", "crossing_on", "crossing_off", "toy_repeat", "dbg_diploid"])
+def test_tables_match_oracle(gpu_lib, oracle, case):
+    rng = np.random.default_rng(3)
+    if case == "linear_high":
+        arrays = D.mock_linear().to_phmm(D.PHMMParams.high_error())
+        reads = [b"CGATC", b"ATTCGTCGT", b"T", b"GGGGGGGG"]
+    elif case.startswith("crossing"):
+        arrays = D.mock_crossing(case.endswith("on")).to_phmm(D.PHMMParams.default())
+        reads = [b"ATTAGGAGCAGCTGATAGGG", b"ATTAGGAGCA", b"TGCTCTGGCGCGAAGATGAG"]
+    elif case == "toy_repeat":
+        sg, k = D.toy_repeat()
+        arrays = sg.to_uniform_phmm(D.PHMMParams.uniform(0.01).with_(n_warmup=k))
+        reads = [b"CCCAG", b"GCAGCAGG", b"TCCCAGCAGCAGCAGGAA"]
+    else:
+        arrays, _ = small_dbg_model(200, 10, 0.02, seed=11)
+        reads = D.sample_reads(arrays, 300, 60, seed=5)[:4]
+        reads.append(bytes(rng.choice(list(b"ACGT"), size=40).tolist()))
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    for read in reads:
+        f, b = gm.forward(read), gm.backward(read)
+        of, ob = om.forward(read), om.backward(read)
+        for i in range(len(read)):
+            m, ins, d, s = of.table(i)
+            floor = max(m.max(), ins.max(), d.max()) - 600.0
+            assert finite_close(f.m[i], m, TOL_TABLE, floor).all(), (case, read, i, "Fm")
+            assert finite_close(f.i[i], ins, TOL_TABLE, floor).all(), (case, read, i, "Fi")
+            assert finite_close(f.d[i], d, TOL_TABLE, floor).all(), (case, read, i, "Fd")
+            assert finite_close(f.scal[i], s, TOL_TABLE).all(), (case, read, i, "Fscal", f.scal[i], s)
+            m, ins, d, s = ob.table(i)
+            floor = max(m.max(), ins.max(), d.max()) - 600.0
+            assert finite_close(b.m[i], m, TOL_TABLE, floor).all(), (case, read, i, "Bm")
+            assert finite_close(b.i[i], ins, TOL_TABLE, floor).all(), (case, read, i, "Bi")
+            assert finite_close(b.d[i], d, TOL_TABLE, floor).all(), (case, read, i, "Bd")
+            assert finite_close(b.scal[i], s, TOL_TABLE).all(), (case, read, i, "Bscal", b.scal[i], s)
+
+
+@pytest.mark.parametrize("n_reads", [1, 3, 8, 37, 70])
+def test_run_dense_matches_oracle(gpu_lib, oracle, n_reads):
+    arrays, _ = small_dbg_model(400, 12, 0.01, seed=21)
+    reads = D.sample_reads(arrays, 10 ** 9, 80, seed=n_reads, max_reads=n_reads)
+    # ragged lengths
+    reads = [r[: max(1, len(r) - (j * 7) % 31)] for j, r in enumerate(reads)]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    lf, lb, nf = gm.run_dense(D.ReadCollection(reads))
+    olf, olb, onf = om.run_dense_reads(reads, n_threads=8)
+    assert np.max(np.abs(lf - olf)) < TOL_LOGP
+    assert np.max(np.abs(lb - olb)) < TOL_LOGP
+    assert np.max(np.abs(nf - onf)) < TOL_FREQ * max(1, n_reads)
+    # posterior mass: about one node per emitted base (Del states and the trailing-deletion
+    # asymmetry between fe and b_init move it by ~p)
+    tot = sum(len(r) for r in reads)
+    assert abs(nf.sum() - tot) < 0.03 * tot
+    # bit-reproducible
+    lf2, lb2, nf2 = gm.run_dense(D.ReadCollection(reads))
+    assert np.array_equal(lf, lf2) and np.array_equal(lb, lb2) and np.array_equal(nf, nf2)
+
+
+def test_workspace_chunking(gpu_lib, oracle):
+    """a tiny workspace limit forces several chunks; results must not change."""
+    arrays, _ = small_dbg_model(300, 12, 0.01, seed=5)
+    reads = D.sample_reads(arrays, 10 ** 9, 50, seed=9, max_reads=40)
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    lf, lb, nf = gm.run_dense(rc)
+    gpu_lib.phmm_set_workspace_limit(4 << 20)
+    try:
+        lf2, lb2, nf2 = gm.run_dense(rc)
+    finally:
+        gpu_lib.phmm_set_workspace_limit(0)
+    assert np.allclose(lf, lf2, atol=1e-12) and np.allclose(lb, lb2, atol=1e-12)
+    assert np.allclose(nf, nf2, atol=1e-10)
+
+
+def test_errors(gpu_lib):
+    with pytest.raises(D.PhmmError):
+        D.ReadCollection([b"ACGT", b""])  # empty read: the reference panics
+    arrays = D.mock_linear().to_phmm(D.PHMMParams.default())
+    arrays.edge_dst = arrays.edge_dst.copy()
+    arrays.edge_dst[0] = 99
+    with pytest.raises(D.PhmmError):
+        D.PHMMModel(arrays)
