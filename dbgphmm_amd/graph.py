@@ -346,90 +346,89 @@ def sample_reads(model: PHMMArrays, n_bases_total: int, state_count: int, seed: 
     """Reads drawn from the PHMM generative model itself (src/hmmv2/sample.rs:270-419):
     Begin -> pick_init_node by init_prob; {Match,Ins,Del} transitions by param; Match emits
     the node base with p_match else one of the other three, Ins emits uniform ACGT; stop after
-    ``state_count`` transitions (ReadLength::StateCount) or when no child has p>0.  Reads
-    are sampled until ``n_bases_total`` bases (sample.rs:223-232).  Our own PRNG stream."""
+    ``state_count`` transitions (ReadLength::StateCount) or when no child has p>0.  Reads are
+    sampled until ``n_bases_total`` bases (ReadAmount::TotalBases, sample.rs:223-232).
+    Our own PRNG stream (numpy PCG64); all reads of a batch are walked in lockstep."""
     p = model.param
     rng = np.random.default_rng(seed)
     n = model.n_nodes
-    # children CSR with linear trans probs
+    # padded child table with cumulative linear trans probs
     order = np.argsort(model.edge_src, kind="stable")
-    csrc = model.edge_src[order]
-    cdst = model.edge_dst[order]
+    csrc = model.edge_src[order].astype(np.int64)
+    cdst = model.edge_dst[order].astype(np.int64)
     cpr = np.exp(model.trans_logp[order])
-    off = np.zeros(n + 1, dtype=np.int64)
-    np.add.at(off, csrc.astype(np.int64) + 1, 1)
-    off = np.cumsum(off)
+    deg = np.bincount(csrc, minlength=n)
+    maxdeg = int(deg.max()) if deg.size else 0
+    off = np.concatenate([[0], np.cumsum(deg)])
+    slot = np.arange(csrc.shape[0]) - off[csrc]
+    child = np.zeros((n, max(maxdeg, 1)), dtype=np.int64)
+    cum = np.zeros((n, max(maxdeg, 1)))
+    child[csrc, slot] = cdst
+    cum[csrc, slot] = cpr
+    cum = np.cumsum(cum, axis=1)
+    tot = cum[:, -1]
     init = np.exp(model.init_logp)
     init_cdf = np.cumsum(init / init.sum())
     e = math.exp
-    tr = {
-        "M": (e(p.p_MM), e(p.p_MI), e(p.p_MD)),
-        "I": (e(p.p_IM), e(p.p_II), e(p.p_ID)),
-        "D": (e(p.p_DM), e(p.p_DI), e(p.p_DD)),
-    }
+    # rows: from-state M, I, D ; cols: to M, to I, to D  (sample.rs:345-386)
+    tr = np.array([[e(p.p_MM), e(p.p_MI), e(p.p_MD)],
+                   [e(p.p_IM), e(p.p_II), e(p.p_ID)],
+                   [e(p.p_DM), e(p.p_DI), e(p.p_DD)]])
     pm = e(p.p_match)
-    acgt = b"ACGT"
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    B, IB, M, I, D, DEAD = 0, 1, 2, 3, 4, 5
     reads: List[bytes] = []
     total = 0
-
-    def pick_child(v: int) -> int:
-        a, b = off[v], off[v + 1]
-        w = cpr[a:b]
-        s = w.sum()
-        if b == a or s <= 0:
-            return -1
-        if b - a == 1:
-            return int(cdst[a])
-        u = rng.random() * s
-        c = np.cumsum(w)
-        return int(cdst[a + int(np.searchsorted(c, u, side="right").clip(0, b - a - 1))])
-
-    def emit_match(v: int) -> int:
-        b = int(model.emission[v])
-        if rng.random() < pm:
-            return b
-        others = [c for c in acgt if c != b]
-        return others[int(rng.integers(0, len(others)))]
-
+    batch = 64
     while total < n_bases_total and (max_reads is None or len(reads) < max_reads):
-        out = bytearray()
-        # MatchBegin (sample.rs:389-401)
-        node = int(np.searchsorted(init_cdf, rng.random(), side="right").clip(0, n - 1))
-        state = "B"
-        n_state = 0
-        while n_state < state_count:
-            if state in ("B", "IB"):
-                pm_, pi_, pd_ = (tr["M"] if state == "B" else tr["I"])
-                u = rng.random() * (pm_ + pi_ + pd_)
-                if u < pi_:
-                    state = "IB"
-                    out.append(acgt[int(rng.integers(0, 4))])
-                elif u < pi_ + pm_:
-                    state = "M"
-                    out.append(emit_match(node))
-                else:
-                    state = "D"
-                if state == "IB":
-                    node = int(np.searchsorted(init_cdf, rng.random(), side="right").clip(0, n - 1))
-            else:
-                child = pick_child(node)
-                if child < 0:
-                    break
-                pm_, pi_, pd_ = tr[state]
-                u = rng.random() * (pm_ + pi_ + pd_)
-                if u < pm_:
-                    state = "M"
-                    node = child
-                    out.append(emit_match(node))
-                elif u < pm_ + pi_:
-                    state = "I"
-                    out.append(acgt[int(rng.integers(0, 4))])
-                else:
-                    state = "D"
-                    node = child
-            n_state += 1
-        if len(out) == 0:
-            continue
-        reads.append(bytes(out))
-        total += len(out)
+        if max_reads is not None:
+            batch = min(batch, max_reads - len(reads))
+        R = batch
+        node = np.searchsorted(init_cdf, rng.random(R), side="right").clip(0, n - 1)
+        state = np.full(R, B)
+        out = np.full((R, state_count), 255, dtype=np.uint8)
+        for step in range(state_count):
+            alive = state != DEAD
+            if not alive.any():
+                break
+            u = rng.random(R)
+            u2 = rng.random(R)
+            u3 = rng.random(R)
+            frm = np.where(state == B, 0, np.where(state == IB, 1, state - 2)).clip(0, 2)
+            w = tr[frm]
+            uu = u * w.sum(axis=1)
+            to_m = uu < w[:, 0]
+            to_i = (~to_m) & (uu < w[:, 0] + w[:, 1])
+            to_d = ~(to_m | to_i)
+            begin = (state == B) | (state == IB)
+            # normal states need a child with p > 0 (sample.rs:430-447)
+            has_child = tot[node] > 0
+            dead_now = alive & ~begin & ~has_child
+            ch_slot = (cum[node] <= (u2 * tot[node])[:, None]).sum(axis=1).clip(0, child.shape[1] - 1)
+            ch = child[node, ch_slot]
+            go = alive & ~dead_now
+            # next node: begin -> the picked init node itself; normal M/D moves to the child
+            new_node = np.where(begin, node, np.where(to_i, node, ch))
+            new_state = np.where(to_m, M, np.where(to_i, np.where(begin, IB, I), D))
+            # emission (picker.rs:21-44)
+            nb = model.emission[new_node]
+            mis = (np.searchsorted(acgt, nb).clip(0, 3) + 1 + (u3 * 3).astype(np.int64).clip(0, 2)) % 4
+            rnd4 = (u3 * 4).astype(np.int64).clip(0, 3)
+            em_match = np.where(rng.random(R) < pm, nb, acgt[mis])
+            base = np.where(to_m, em_match, np.where(to_i, acgt[rnd4], 255)).astype(np.uint8)
+            out[go, step] = base[go]
+            # InsBegin re-picks the init node for its next transition (sample.rs:402-414)
+            repick = np.searchsorted(init_cdf, rng.random(R), side="right").clip(0, n - 1)
+            node = np.where(go, np.where(begin & to_i, repick, new_node), node)
+            state = np.where(go, new_state, DEAD)
+        for r in range(R):
+            row = out[r]
+            seq = row[row != 255].tobytes()
+            if not seq:
+                continue
+            reads.append(seq)
+            total += len(seq)
+            if total >= n_bases_total or (max_reads is not None and len(reads) >= max_reads):
+                break
+        batch = min(batch * 2, 4096)
     return reads
