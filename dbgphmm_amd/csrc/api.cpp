@@ -39,6 +39,18 @@ void copy_out(void *dst, const void *src_dev, size_t bytes) {
     HIP_CHECK(hipStreamSynchronize(current_stream()));
 }
 
+void put_doubles(double *dst, const double *src, size_t n) {
+    if (!dst || !n) return;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeDevice) {
+        HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, current_stream()));
+        HIP_CHECK(hipStreamSynchronize(current_stream()));
+    } else {
+        (void)hipGetLastError();
+        std::memcpy(dst, src, n * sizeof(double));
+    }
+}
+
 template <class F> static int guarded(F &&f) {
     try {
         f();
@@ -278,6 +290,10 @@ int phmm_mappings_create(const phmm_reads *reads, const uint64_t *pos_off, const
         mp->nodes.assign(nodes, nodes + te);
         if (logp) mp->logp.assign(logp, logp + te);
         else mp->logp.assign(te, 0.0);
+        mp->read_max_list.assign(reads->R, 0);
+        for (uint64_t r = 0; r < reads->R; r++)
+            for (uint64_t i = reads->off[r]; i < reads->off[r + 1]; i++)
+                mp->read_max_list[r] = std::max<uint32_t>(mp->read_max_list[r], (uint32_t)(pos_off[i + 1] - pos_off[i]));
         *out = mp;
     });
     if (rc != PHMM_OK) delete mp;
@@ -294,5 +310,56 @@ int phmm_mappings_export(const phmm_mappings *mp, uint64_t *pos_off, uint32_t *n
     });
 }
 void phmm_mappings_destroy(phmm_mappings *mp) { delete mp; }
+
+// Mappings::to_node_freqs (hint.rs:161-171): freq[v] = sum of linear probs over all lists
+int phmm_mappings_node_freqs(const phmm_mappings *mp, uint32_t n_nodes, double *out) {
+    return guarded([&] {
+        if (!mp || !out) PHMM_THROW(PHMM_EINVAL, "NULL argument");
+        std::vector<double> f(n_nodes, 0.0);
+        for (size_t a = 0; a < mp->nodes.size(); a++) {
+            if (mp->nodes[a] >= n_nodes) PHMM_THROW(PHMM_EINVAL, "mapping node out of range");
+            f[mp->nodes[a]] += std::exp(mp->logp[a]);
+        }
+        put_doubles(out, f.data(), n_nodes);
+    });
+}
+
+static void check_mapping_nodes(const phmm_model *m, const phmm_mappings *mp, const phmm_reads *reads) {
+    if (mp->R != reads->R || mp->total_pos != reads->total || mp->read_off != reads->off)
+        PHMM_THROW(PHMM_EINVAL, "mappings were built for a different read set");
+    for (uint32_t v : mp->nodes)
+        if (v >= m->N) PHMM_THROW(PHMM_EINVAL, "mapping node out of range");
+}
+
+int phmm_full_prob_reads(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, int use_max_ratio,
+                         double *out_logp, double *out_total) {
+    return guarded([&] {
+        if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
+        if (reads->R == 0) {
+            const double zero = 0.0;  // empty product = Prob::one()
+            put_doubles(out_total, &zero, 1);
+            return;
+        }
+        if (mp) {
+            check_mapping_nodes(m, mp, reads);
+            full_prob_reads_hinted(m, reads, mp, 1, nullptr, nullptr, out_logp, out_total);
+        } else {
+            (void)use_max_ratio;
+            PHMM_THROW(PHMM_EINTERNAL, "forward_sparse_score_only without mappings is not built yet");
+        }
+    });
+}
+
+int phmm_full_prob_reads_candidates(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
+                                    const double *init_logp, const double *trans_logp, double *out_logp,
+                                    double *out_total) {
+    return guarded([&] {
+        if (!m || !reads || !mp) PHMM_THROW(PHMM_EINVAL, "NULL model, reads or mappings");
+        if (n_cand == 0) return;
+        if (!init_logp || (m->E && !trans_logp)) PHMM_THROW(PHMM_EINVAL, "NULL candidate arrays");
+        check_mapping_nodes(m, mp, reads);
+        full_prob_reads_hinted(m, reads, mp, n_cand, init_logp, trans_logp, out_logp, out_total);
+    });
+}
 
 }  // extern "C"

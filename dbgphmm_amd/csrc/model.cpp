@@ -193,8 +193,29 @@ void model_upload(phmm_model *m) {
     d.chi_node.upload(m->chi_node.data(), sizeof(uint32_t) * E);
     d.chi_edge.upload(m->chi_edge.data(), sizeof(uint32_t) * E);
     d.chi_w.upload(cw.data(), sizeof(double) * E);
+    d.trans_lin.upload(tlin.data(), sizeof(double) * E);
+    d.max_degree = 0;
+    for (uint32_t v = 0; v < N; v++)
+        d.max_degree = std::max(d.max_degree, std::max(m->par_off[v + 1] - m->par_off[v], m->chi_off[v + 1] - m->chi_off[v]));
+    d.logib_len = 0;  // parameters may have changed
     // the host vectors above die at scope exit: make sure the async copies are done
     HIP_CHECK(hipStreamSynchronize(current_stream()));
+}
+
+// forward InsBegin chain in the log domain: ib_0 = p_r*(p_MI*1 + p_II*0); ib_i = p_r*p_II*ib_{i-1}
+// (fib, forward.rs:541-545 with f_init / fmb, forward.rs:255-266, 531-533)
+void ensure_logib(phmm_model *m, size_t len) {
+    if (m->dev.logib_len >= len) return;
+    std::vector<double> v(len);
+    const phmm_params &p = m->params;
+    double ib = p.p_random + p.p_MI;
+    for (size_t i = 0; i < len; i++) {
+        v[i] = ib;
+        ib = p.p_random + p.p_II + ib;
+    }
+    m->dev.logib.upload(v.data(), len * sizeof(double));
+    HIP_CHECK(hipStreamSynchronize(current_stream()));
+    m->dev.logib_len = len;
 }
 
 }  // namespace phmm

@@ -101,6 +101,10 @@ struct ModelDev {
     DevBuf par_off, par_node, par_w;  // u32[N+1], u32[E], f64[E]
     DevBuf chi_off, chi_node, chi_w;
     DevBuf par_edge, chi_edge;        // u32[E] edge ids (candidate batches index trans by edge)
+    DevBuf trans_lin;                 // f64[E] by edge id
+    DevBuf logib;                     // f64[logib_len] forward InsBegin chain (log)
+    size_t logib_len = 0;
+    uint32_t max_degree = 0;
 };
 
 }  // namespace phmm
@@ -125,6 +129,9 @@ struct phmm_reads {
     std::vector<uint8_t> bases;
     std::vector<uint64_t> off;
     uint64_t max_len = 0;
+    // lazily uploaded device copies (per device of first use)
+    mutable phmm::DevBuf d_bases, d_off;
+    mutable bool on_device = false;
 };
 
 struct phmm_mappings {
@@ -133,6 +140,9 @@ struct phmm_mappings {
     std::vector<uint64_t> pos_off;   // [total_pos+1]
     std::vector<uint32_t> nodes;
     std::vector<double> logp;
+    std::vector<uint32_t> read_max_list;  // [R] longest node list of each read
+    mutable phmm::DevBuf d_pos_off, d_nodes;
+    mutable bool on_device = false;
 };
 
 namespace phmm {
@@ -151,6 +161,12 @@ void model_upload(phmm_model *m);        // closures + device arrays
 // dense driver (dense.hip)
 void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb,
                double *out_nf);
+// sparse / hinted drivers (sparse.hip)
+void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
+                            const double *init_logp, const double *trans_logp, double *out_logp,
+                            double *out_total);
+void ensure_logib(phmm_model *m, size_t len);
+void put_doubles(double *dst, const double *src_host, size_t n);
 void dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i,
                   double *f_d, double *f_scal, double *b_m, double *b_i, double *b_d,
                   double *b_scal);

@@ -1,8 +1,250 @@
-// placeholder, replaced below in this round
-#include "phmm_internal.h"
-extern "C" {
-int phmm_mappings_node_freqs(const phmm_mappings *, uint32_t, double *) { return phmm::fail(PHMM_EINTERNAL, "not built yet"); }
-int phmm_full_prob_reads(phmm_model *, const phmm_reads *, const phmm_mappings *, int, double *, double *) { return phmm::fail(PHMM_EINTERNAL, "not built yet"); }
-int phmm_full_prob_reads_candidates(phmm_model *, const phmm_reads *, const phmm_mappings *, uint32_t, const double *, const double *, double *, double *) { return phmm::fail(PHMM_EINTERNAL, "not built yet"); }
-int phmm_generate_mappings(phmm_model *, const phmm_reads *, const phmm_mappings *, int, phmm_mappings **, double *) { return phmm::fail(PHMM_EINTERNAL, "not built yet"); }
+// Sparse (active-node frontier) kernels: one wave64 per (read[, candidate]).
+//
+// hinted_score_kernel = PHMMModel::forward_with_mapping_score_only
+//   (src/hmmv2/forward.rs:79-89): f_step over mapping.nodes(i) for every read position,
+//   non-adaptive, returning table.e of the last position.  It is the inner loop of
+//   `infer`: to_full_prob_reads (src/hmmv2/freq.rs:175-192) called once per candidate
+//   copy-number vector per iteration (src/multi_dbg/posterior.rs:483-515).  The grid is
+//   (reads x candidates): topology, reads and mappings are shared, only init/trans differ.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "sparse_dev.h"
+
+namespace phmm {
+
+struct HintedArgs {
+    SparseModel M;
+    const double *init_c;   // [C][N] linear
+    const double *trans_c;  // [C][E] linear
+    uint32_t E;
+    const uint8_t *bases;
+    const uint64_t *read_off;
+    const uint64_t *map_pos_off;
+    const uint32_t *map_nodes;
+    const uint32_t *read_ids;  // reads of this capacity class
+    uint64_t R;
+    double *out_logp;  // [C][R]
+    uint32_t *err;     // [C][R]
+};
+
+template <int CAP, int LPN>
+__global__ void __launch_bounds__(64) hinted_score_kernel(const HintedArgs a) {
+    __shared__ Col<CAP> cols[2];
+    __shared__ int16_t lnk_slot[CAP * LPN];
+    __shared__ double lnk_w[CAP * LPN];
+    __shared__ double dA[CAP], dB[CAP];
+    const uint32_t rd = a.read_ids[blockIdx.x];
+    const uint32_t cand = blockIdx.y;
+    SparseModel M = a.M;
+    M.init = a.init_c + (size_t)cand * M.N;
+    M.trans = a.trans_c + (size_t)cand * a.E;
+    const uint64_t b0 = a.read_off[rd];
+    const int len = (int)(a.read_off[rd + 1] - b0);
+    uint32_t err = 0;
+    if (threadIdx.x == 0) {
+        cols[0].n = cols[0].na = 0;
+        cols[0].E = 0;
+        cols[1].n = cols[1].na = 0;
+        cols[1].E = 0;
+    }
+    __syncthreads();
+    int pos = 0;
+    for (; pos < len; pos++) {
+        const uint64_t o0 = a.map_pos_off[b0 + pos], o1 = a.map_pos_off[b0 + pos + 1];
+        const int n = (int)(o1 - o0);
+        if (n > CAP) {
+            err |= SP_ERR_CAPACITY;
+            break;
+        }
+        err |= fwd_list_step<CAP, LPN>(M, cols[(pos + 1) & 1], cols[pos & 1], a.map_nodes + o0, n, a.bases[b0 + pos],
+                                       pos == 0, pos, lnk_slot, lnk_w, dA, dB);
+    }
+    for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
+    const double lp = err ? NAN : col_log_end(M, cols[(len - 1) & 1]);
+    if (threadIdx.x == 0) {
+        a.out_logp[(size_t)cand * a.R + rd] = lp;
+        a.err[(size_t)cand * a.R + rd] = err;
+    }
+}
+
+__global__ void __launch_bounds__(256) exp_kernel(const double *in, double *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const double v = in[i];
+        out[i] = v == -INFINITY ? 0.0 : exp(v);
+    }
+}
+
+namespace {
+
+void upload_reads(const phmm_reads *r) {
+    if (r->on_device) return;
+    r->d_bases.upload(r->bases.data(), r->bases.size());
+    r->d_off.upload(r->off.data(), r->off.size() * sizeof(uint64_t));
+    HIP_CHECK(hipStreamSynchronize(current_stream()));
+    r->on_device = true;
+}
+void upload_mappings(const phmm_mappings *mp) {
+    if (mp->on_device) return;
+    mp->d_pos_off.upload(mp->pos_off.data(), mp->pos_off.size() * sizeof(uint64_t));
+    mp->d_nodes.upload(mp->nodes.data(), std::max<size_t>(mp->nodes.size(), 1) * sizeof(uint32_t));
+    HIP_CHECK(hipStreamSynchronize(current_stream()));
+    mp->on_device = true;
+}
+
+SparseModel sparse_model(const phmm_model *m) {
+    const ModelDev &d = m->dev;
+    SparseModel s{};
+    s.N = (int)m->N;
+    s.emis = d.emis.as<uint8_t>();
+    s.init = d.init.as<double>();
+    s.par_off = d.par_off.as<uint32_t>();
+    s.par_node = d.par_node.as<uint32_t>();
+    s.par_edge = d.par_edge.as<uint32_t>();
+    s.chi_off = d.chi_off.as<uint32_t>();
+    s.chi_node = d.chi_node.as<uint32_t>();
+    s.chi_edge = d.chi_edge.as<uint32_t>();
+    s.trans = d.trans_lin.as<double>();
+    s.lp = m->lin;
+    s.logib = d.logib.as<double>();
+    return s;
+}
+
+struct EvTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on;
+    explicit EvTimer(bool on_) : on(on_) {
+        if (on) {
+            HIP_CHECK(hipEventCreate(&a));
+            HIP_CHECK(hipEventCreate(&b));
+            HIP_CHECK(hipEventRecord(a, current_stream()));
+        }
+    }
+    ~EvTimer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    double stop() {
+        if (!on) return 0.0;
+        HIP_CHECK(hipEventRecord(b, current_stream()));
+        HIP_CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        return ms;
+    }
+};
+
+template <int CAP, int LPN> void launch_hinted(const HintedArgs &a, uint32_t n_reads, uint32_t n_cand) {
+    if (!n_reads) return;
+    hipLaunchKernelGGL((hinted_score_kernel<CAP, LPN>), dim3(n_reads, n_cand), dim3(64), 0, current_stream(), a);
+}
+
+}  // namespace
+
+void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
+                            const double *init_logp, const double *trans_logp, double *out_logp,
+                            double *out_total) {
+    hipStream_t s = current_stream();
+    CallStats &st = stats();
+    st = CallStats();
+    const uint64_t R = reads->R;
+    const uint32_t N = m->N, E = m->E;
+    if (m->dev.max_degree > 8)
+        PHMM_THROW(PHMM_EINVAL, "sparse path supports node degree <= 8 (MultiDbg MAX_DEGREE is 5)");
+    upload_reads(reads);
+    upload_mappings(mp);
+    ensure_logib(m, reads->max_len + 1);
+
+    // candidate probabilities in the linear domain: [C][N], [C][E]
+    DevBuf cand_init, cand_trans, staging;
+    const double *d_init = m->dev.init.as<double>();
+    const double *d_trans = m->dev.trans_lin.as<double>();
+    if (init_logp) {
+        const size_t ni = (size_t)n_cand * N, ne = (size_t)n_cand * E;
+        staging.reserve(std::max(ni, ne) * sizeof(double));
+        cand_init.reserve(ni * sizeof(double));
+        cand_trans.reserve(std::max<size_t>(ne, 1) * sizeof(double));
+        HIP_CHECK(hipMemcpyAsync(staging.p, init_logp, ni * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(exp_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, s, staging.as<double>(),
+                           cand_init.as<double>(), ni);
+        if (ne) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(hipMemcpyAsync(staging.p, trans_logp, ne * sizeof(double), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(exp_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, staging.as<double>(),
+                               cand_trans.as<double>(), ne);
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        d_init = cand_init.as<double>();
+        d_trans = cand_trans.as<double>();
+    }
+
+    // capacity classes by the longest node list of each read
+    std::vector<uint32_t> cls[3];
+    uint64_t cells = 0;
+    for (uint64_t r = 0; r < R; r++) {
+        const uint32_t mx = mp->read_max_list[r];
+        cls[mx <= 64 ? 0 : (mx <= 128 ? 1 : 2)].push_back((uint32_t)r);
+        cells += mp->pos_off[reads->off[r + 1]] - mp->pos_off[reads->off[r]];
+    }
+    DevBuf d_ids, d_out, d_err;
+    d_ids.reserve(R * sizeof(uint32_t));
+    d_out.reserve((size_t)n_cand * R * sizeof(double));
+    d_err.reserve((size_t)n_cand * R * sizeof(uint32_t));
+    std::vector<double> h_out((size_t)n_cand * R);
+    std::vector<uint32_t> h_err((size_t)n_cand * R);
+
+    HintedArgs a{};
+    a.M = sparse_model(m);
+    a.init_c = d_init;
+    a.trans_c = d_trans;
+    a.E = E;
+    a.bases = reads->d_bases.as<uint8_t>();
+    a.read_off = reads->d_off.as<uint64_t>();
+    a.map_pos_off = mp->d_pos_off.as<uint64_t>();
+    a.map_nodes = mp->d_nodes.as<uint32_t>();
+    a.read_ids = d_ids.as<uint32_t>();
+    a.R = R;
+    a.out_logp = d_out.as<double>();
+    a.err = d_err.as<uint32_t>();
+
+    EvTimer tm(timing_enabled());
+    for (int c = 0; c < 3; c++) {
+        if (cls[c].empty()) continue;
+        HIP_CHECK(hipMemcpyAsync(d_ids.p, cls[c].data(), cls[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        if (c == 0) launch_hinted<64, 2>(a, (uint32_t)cls[c].size(), n_cand);
+        else if (c == 1) launch_hinted<128, 4>(a, (uint32_t)cls[c].size(), n_cand);
+        else launch_hinted<400, 8>(a, (uint32_t)cls[c].size(), n_cand);
+        HIP_CHECK(hipGetLastError());
+        st.launches[2]++;
+        HIP_CHECK(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(h_err.data(), d_err.p, h_err.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        // reads whose in-list fan-in exceeded this class's link budget are promoted
+        for (uint32_t rd : cls[c]) {
+            uint32_t e = 0;
+            for (uint32_t k = 0; k < n_cand; k++) e |= h_err[(size_t)k * R + rd];
+            if (!e) continue;
+            if (e & SP_ERR_DUPLICATE) PHMM_THROW(PHMM_EINVAL, "duplicate node in a mapping list");
+            if ((e & (SP_ERR_LINKS | SP_ERR_CAPACITY)) && c < 2) cls[c + 1].push_back(rd);
+            else PHMM_THROW(PHMM_ECAPACITY, "mapping list needs more than 400 slots / 8 in-list parents");
+        }
+    }
+    st.ms[2] += tm.stop();
+    st.cells[2] = cells * n_cand;
+
+    std::vector<double> tot(n_cand, 0.0);
+    for (uint32_t k = 0; k < n_cand; k++)
+        for (uint64_t r = 0; r < R; r++) tot[k] += h_out[(size_t)k * R + r];  // rayon .product(): sum of logs
+    put_doubles(out_logp, h_out.data(), h_out.size());
+    put_doubles(out_total, tot.data(), n_cand);
+}
+
+}  // namespace phmm
+
+extern "C" int phmm_generate_mappings(phmm_model *, const phmm_reads *, const phmm_mappings *, int, phmm_mappings **,
+                                      double *) {
+    return phmm::fail(PHMM_EINTERNAL, "not built yet");
 }

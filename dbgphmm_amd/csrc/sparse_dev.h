@@ -1,0 +1,237 @@
+// Device-side building blocks of the sparse (active-node frontier) kernels: one wave64
+// per (read[, candidate]); the frontier of the previous and the current read position
+// live in LDS as insertion-ordered (node, m, i, d) lists plus an open-addressing hash
+// node -> slot, mirroring the reference's `SparseVec<Prob, NodeIndex, 400>` tables
+// (src/hmmv2/table.rs:28, 42-73).  Values are linear probabilities scaled by 2^-E per
+// column (exact power-of-two rescale after every column), so ln P = ln(sum) + E ln 2.
+#pragma once
+
+#include "phmm_internal.h"
+
+namespace phmm {
+
+static constexpr uint32_t H_EMPTY = 0xffffffffu;
+static constexpr double SP_LN2 = 0.693147180559945309417232121458;
+
+// error bits reported per read
+enum : uint32_t {
+    SP_ERR_LINKS = 1u,      // more in-list parents than LPN: rerun in a bigger class
+    SP_ERR_CAPACITY = 2u,   // frontier needs more than CAP slots: rerun in a bigger class / ECAPACITY
+    SP_ERR_DUPLICATE = 4u,  // duplicate node in a mapping list
+    SP_ERR_DEGREE = 8u      // node degree above the supported maximum
+};
+
+template <int CAP> struct HashSize {
+    static constexpr int LOG2 = CAP <= 64 ? 8 : (CAP <= 128 ? 9 : 10);
+    static constexpr int N = 1 << LOG2;
+};
+
+template <int CAP> struct Col {
+    double m[CAP], i[CAP], d[CAP];
+    uint32_t id[CAP];
+    uint32_t hkey[HashSize<CAP>::N];
+    uint16_t hslot[HashSize<CAP>::N];
+    int n;   // stored entries (the reference's nodevec elements)
+    int na;  // entries that carry m/i (the active list handed to f_step / b_step)
+    int E;   // column exponent: true value = stored * 2^E
+};
+
+template <int CAP> __device__ __forceinline__ uint32_t hash_of(uint32_t id) {
+    return (id * 2654435761u) >> (32 - HashSize<CAP>::LOG2);
+}
+template <int CAP> __device__ __forceinline__ void hash_clear(Col<CAP> &c) {
+    for (int h = threadIdx.x; h < HashSize<CAP>::N; h += 64) c.hkey[h] = H_EMPTY;
+}
+// returns false when the id is already present (slot is left unchanged)
+template <int CAP> __device__ __forceinline__ bool hash_insert(Col<CAP> &c, uint32_t id, int slot) {
+    uint32_t h = hash_of<CAP>(id);
+    for (;;) {
+        const uint32_t old = atomicCAS(&c.hkey[h], H_EMPTY, id);
+        if (old == H_EMPTY) {
+            c.hslot[h] = (uint16_t)slot;
+            return true;
+        }
+        if (old == id) return false;
+        h = (h + 1) & (HashSize<CAP>::N - 1);
+    }
+}
+template <int CAP> __device__ __forceinline__ int hash_find(const Col<CAP> &c, uint32_t id) {
+    uint32_t h = hash_of<CAP>(id);
+    for (;;) {
+        const uint32_t k = c.hkey[h];
+        if (k == id) return (int)c.hslot[h];
+        if (k == H_EMPTY) return -1;
+        h = (h + 1) & (HashSize<CAP>::N - 1);
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ int wave_isum(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int wave_iscan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int sp_exp_of(double v) {  // v*2^-e in [0.5,1); 0 for v == 0
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const int be = (int)((bits >> 52) & 0x7ff);
+    if (bits == 0ull) return 0;
+    if (be == 0) return -1022;
+    return be - 1022;
+}
+__device__ __forceinline__ double sp_pow2(int e) {
+    return __longlong_as_double((long long)(e + 1023) << 52);
+}
+
+// What a sparse kernel needs to know about the model (all linear domain).
+struct SparseModel {
+    int N;
+    const uint8_t *emis;
+    const double *init;  // [N] (per candidate: offset applied by the caller)
+    const uint32_t *par_off, *par_node, *par_edge;
+    const uint32_t *chi_off, *chi_node, *chi_edge;
+    const double *trans;  // [E] by edge id (per candidate: offset applied by the caller)
+    LinParams lp;
+    const double *logib;  // forward InsBegin chain (log), [>= max read length]
+};
+
+// Rescale a freshly computed column so that its maximum lies in [0.5, 1).
+template <int CAP> __device__ __forceinline__ void col_rescale(Col<CAP> &c, int E_in, double extra_max) {
+    double mx = extra_max;
+    for (int j = threadIdx.x; j < c.n; j += 64) mx = fmax(mx, fmax(fmax(c.m[j], c.i[j]), c.d[j]));
+    mx = wave_max(mx);
+    const int e = sp_exp_of(mx);
+    const double s = sp_pow2(-e);
+    for (int j = threadIdx.x; j < c.n; j += 64) {
+        c.m[j] *= s;
+        c.i[j] *= s;
+        c.d[j] *= s;
+    }
+    if (threadIdx.x == 0) c.E = E_in + e;
+}
+
+// ---------------------------------------------------------------------------------
+// One forward column over a GIVEN node list (non-adaptive f_step: forward.rs:276-306 with
+// is_adaptive = false, i.e. forward_with_mapping*, forward.rs:51-89):
+//   fm (337-359), fi (378-388), fib (541-545), fd = fd0 + G x fdt restricted to the list
+//   (423-524), values of nodes outside the list read as 0 (SparseVec default).
+// prev: the previous column (cur.n == 0 and first == true for f_init).
+// lnk_slot/lnk_w: LDS scratch [CAP*LPN]; dA/dB: LDS scratch [CAP].
+// Returns error bits (wave-uniform).
+template <int CAP, int LPN>
+__device__ uint32_t fwd_list_step(const SparseModel &M, const Col<CAP> &prev, Col<CAP> &cur, const uint32_t *list,
+                                  int n, uint8_t x, bool first, int pos, int16_t *lnk_slot, double *lnk_w,
+                                  double *dA, double *dB) {
+    const LinParams &lp = M.lp;
+    uint32_t err = 0;
+    hash_clear(cur);
+    if (threadIdx.x == 0) {
+        cur.n = n;
+        cur.na = n;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const uint32_t k = list[j];
+        cur.id[j] = k;
+        if (!hash_insert(cur, k, j)) err |= SP_ERR_DUPLICATE;
+    }
+    __syncthreads();
+    // InsBegin of the previous column in the previous column's scale (fib, forward.rs:541-545)
+    const double ibs = first ? 0.0 : exp(M.logib[pos - 1] - (double)prev.E * SP_LN2);
+    const double c_begin = first ? lp.p_MM : lp.p_IM * ibs;  // p_MM*mb' + p_IM*ib'
+    // fib of THIS column, same scale:  ib = p_r (p_MI mb' + p_II ib')
+    const double ib_cur = first ? lp.p_random * lp.p_MI : lp.p_random * lp.p_II * ibs;
+    const double c_del = lp.p_ID * ib_cur;  // fd0 from_begin: p_MD*mb + p_ID*ib with mb = 0
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const uint32_t k = cur.id[j];
+        const double pe = M.emis[k] == x ? lp.p_match : lp.p_mismatch;
+        double acc = 0.0;
+        int nl = 0;
+        const uint32_t a0 = M.par_off[k], a1 = M.par_off[k + 1];
+        for (uint32_t a = a0; a < a1; a++) {
+            const uint32_t l = M.par_node[a];
+            const double w = M.trans[M.par_edge[a]];
+            if (w == 0.0) continue;
+            if (!first) {
+                const int ps = hash_find(prev, l);
+                if (ps >= 0) acc += w * (lp.p_MM * prev.m[ps] + lp.p_IM * prev.i[ps] + lp.p_DM * prev.d[ps]);
+            }
+            const int cs = hash_find(cur, l);
+            if (cs >= 0) {
+                if (nl < LPN) {
+                    lnk_slot[j * LPN + nl] = (int16_t)cs;
+                    lnk_w[j * LPN + nl] = w;
+                    nl++;
+                } else err |= SP_ERR_LINKS;
+            }
+        }
+        for (int q = nl; q < LPN; q++) lnk_slot[j * LPN + q] = -1;
+        const double in = M.init[k];
+        double inew = 0.0;
+        if (!first) {
+            const int os = hash_find(prev, k);
+            if (os >= 0) inew = lp.p_random * (lp.p_MI * prev.m[os] + lp.p_II * prev.i[os] + lp.p_DI * prev.d[os]);
+        }
+        const double mnew = pe * (acc + in * c_begin);
+        cur.m[j] = mnew;
+        cur.i[j] = inew;
+        dA[j] = lp.p_MD * mnew + lp.p_ID * inew;  // g
+    }
+    __syncthreads();
+    // fd0 (forward.rs:480-501) then n_max_gaps x fdt (510-524), restricted to the list
+    double *src = dA, *dst = dB;
+    for (int t = 0; t <= lp.n_max_gaps; t++) {
+        for (int j = threadIdx.x; j < n; j += 64) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < LPN; q++) {
+                const int cs = lnk_slot[j * LPN + q];
+                if (cs >= 0) s += lnk_w[j * LPN + q] * src[cs];
+            }
+            if (t == 0) {
+                s += M.init[cur.id[j]] * c_del;
+                cur.d[j] = s;
+            } else {
+                s *= lp.p_DD;
+                cur.d[j] += s;
+            }
+            dst[j] = s;
+        }
+        __syncthreads();
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    col_rescale(cur, first ? 0 : prev.E, ib_cur);
+    __syncthreads();
+    return err;
+}
+
+// fe (forward.rs:554-558): ln(p_end * sum over the active list of m+i+d) + E ln2
+template <int CAP> __device__ __forceinline__ double col_log_end(const SparseModel &M, const Col<CAP> &c) {
+    double s = 0.0;
+    for (int j = threadIdx.x; j < c.na; j += 64) s += c.m[j] + c.i[j] + c.d[j];
+    s = wave_sum(s);
+    return log(M.lp.p_end * s) + (double)c.E * SP_LN2;
+}
+
+}  // namespace phmm

@@ -147,8 +147,14 @@ void orc_model_destroy(orc_model *m) {
  * Restatement of `sparsevec::SparseVec<Prob, NodeIndex, 400>` from its call sites
  * (table.rs:87-89,106-112,121,128,139,199-211,309-338).  Dense = Vec of len values;
  * sparse = insertion-ordered (index,value) pairs, capacity 400, reads of absent
- * indices give the default, writes insert.  Overflow sets an error (the reference's
- * ArrayVec would panic). */
+ * indices give the default, writes insert.
+ *
+ * Capacity overflow (UNPINNED: sparsevec@3634d27 is not vendored).  In the reference's
+ * production flow the adaptive Del sweeps right after the dense->sparse switch insert
+ * up to 6 x |top| <= 1200 distinct nodes into one vector (forward.rs:436-465 with
+ * |top| <= warmup_threshold = 200), so an overflowing insert cannot be fatal there.
+ * Default here: the insert is DROPPED (the write goes to a scratch slot, later reads
+ * give the default).  orc_set_overflow_is_error(1) turns it into an error instead. */
 typedef struct {
     int dense;
     uint32_t len;
@@ -159,12 +165,12 @@ typedef struct {
     double *val;
 } nvec;
 
-static int g_overflow_dummy_init = 0;
+static int g_overflow_is_error = 0;
 static __thread int t_overflow = 0;
 static __thread double t_sink;
+void orc_set_overflow_is_error(int on) { g_overflow_is_error = on; }
 
 static void nv_init(nvec *v, uint32_t len, double dflt, int dense) {
-    (void)g_overflow_dummy_init;
     v->dense = dense;
     v->len = len;
     v->dflt = dflt;
@@ -192,7 +198,8 @@ static inline double *nv_ref(nvec *v, uint32_t i) {
     for (int j = 0; j < v->n; j++)
         if (v->idx[j] == i) return &v->val[j];
     if (v->n >= CAP) {
-        t_overflow = 1;
+        if (g_overflow_is_error) t_overflow = 1;
+        t_sink = v->dflt;
         return &t_sink;
     }
     if (!v->idx) {

@@ -54,6 +54,8 @@ typedef struct orc_mapping_view {
 } orc_mapping_view;
 
 const char *orc_last_error(void);
+/* SparseVec capacity overflow: 0 (default) = drop the insert, 1 = fail the call. */
+void orc_set_overflow_is_error(int on);
 
 /* params.rs:73-113 (`new`, arguments are LINEAR probabilities) and 116-125 (`uniform`). */
 void orc_params_new(double p_mismatch, double p_gap_open, double p_gap_ext, double p_end,

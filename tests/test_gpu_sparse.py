@@ -1,0 +1,111 @@
+"""GPU parity: hinted (mapping-restricted) forward = the inner loop of `infer`
+(forward_with_mapping_score_only, forward.rs:79-89; to_full_prob_reads, freq.rs:175-192)."""
+import numpy as np
+import pytest
+
+import dbgphmm_amd as D
+from helpers import small_dbg_model
+
+pytestmark = pytest.mark.gpu
+TOL_LOGP = 1e-9  # BASELINE.json bar: |delta ln P(R|X)| < 1e-6 per read
+
+
+def _setup(oracle, genome_len=600, k=12, p=0.01, n_reads=24, seed=3, read_len=120):
+    arrays, sg = small_dbg_model(genome_len, k, p, seed=seed)
+    reads = D.sample_reads(arrays, 10 ** 9, read_len, seed=seed + 1, max_reads=n_reads)
+    reads = [r[: max(5, len(r) - (j * 5) % 23)] for j, r in enumerate(reads)]
+    om = oracle.Model(arrays)
+    (po, nd, lp), nf = om.generate_mappings(reads, None, True, n_threads=8)
+    return arrays, sg, reads, om, (po, nd, lp)
+
+
+def test_hinted_forward_matches_oracle(gpu_lib, oracle):
+    arrays, sg, reads, om, mp = _setup(oracle)
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    gmp = D.Mappings.from_arrays(rc, *mp)
+    tot, lp = gm.to_full_prob_reads(rc, gmp)
+    olp = om.full_prob_reads(reads, mp, True, n_threads=8)
+    assert np.max(np.abs(lp - olp)) < TOL_LOGP
+    assert abs(tot - olp.sum()) < TOL_LOGP * len(reads)
+    # the hinted score is close to the dense one (reference: hmmv2/tests/dbg.rs:44-45, 1e-4 on the total)
+    lf, _, _ = gm.run_dense(rc, False, False)
+    assert abs(lf.sum() - tot) < 1e-4 * len(reads)
+
+
+def test_hinted_forward_top_k_lists(gpu_lib, oracle):
+    """short fixed-size lists (to_mapping(n_active)) exercise nodes outside the list."""
+    arrays, sg, reads, om, _ = _setup(oracle, n_reads=10, seed=9)
+    gm = D.PHMMModel(arrays)
+    pos_off, nodes = [0], []
+    for r in reads:
+        m = om.run(r).to_mapping(3)
+        for i in range(len(r)):
+            nodes.extend(m.nodes(i))
+            pos_off.append(len(nodes))
+    mp = (np.array(pos_off, dtype=np.uint64), np.array(nodes, dtype=np.uint32), np.zeros(len(nodes)))
+    rc = D.ReadCollection(reads)
+    tot, lp = gm.to_full_prob_reads(rc, D.Mappings.from_arrays(rc, *mp))
+    olp = om.full_prob_reads(reads, mp, True, n_threads=8)
+    assert np.max(np.abs(lp - olp)) < TOL_LOGP
+
+
+def test_candidate_batch(gpu_lib, oracle):
+    """C candidate copy-number vectors on one topology (posterior.rs:483-515)."""
+    arrays, sg, reads, om, mp = _setup(oracle, n_reads=12, seed=5)
+    rng = np.random.default_rng(0)
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    gmp = D.Mappings.from_arrays(rc, *mp)
+    inits, transs, expect = [], [], []
+    for c in range(5):
+        sg2 = D.SeqGraph(sg.copy_num.copy(), sg.base, sg.edge_src, sg.edge_dst, None)
+        flip = rng.integers(0, sg2.copy_num.shape[0], size=8)
+        sg2.copy_num[flip] = rng.integers(0, 4, size=8)
+        a2 = D.vectorised_to_phmm(sg2, arrays.param, 0)
+        inits.append(a2.init_logp)
+        transs.append(a2.trans_logp)
+        expect.append(oracle.Model(a2).full_prob_reads(reads, mp, True, n_threads=8))
+    tot, lp = gm.to_full_prob_reads_candidates(rc, gmp, np.stack(inits), np.stack(transs))
+    expect = np.stack(expect)
+    both_inf = np.isneginf(lp) & np.isneginf(expect)
+    with np.errstate(invalid="ignore"):
+        assert np.all(both_inf | (np.abs(lp - expect) < TOL_LOGP))
+    # set_probs + single evaluation agrees with the batched one
+    gm.set_probs(inits[2], transs[2])
+    t2, lp2 = gm.to_full_prob_reads(rc, gmp)
+    with np.errstate(invalid="ignore"):
+        assert np.all((np.isneginf(lp2) & np.isneginf(lp[2])) | (np.abs(lp2 - lp[2]) < 1e-12))
+
+
+def test_long_lists_use_bigger_class(gpu_lib, oracle):
+    """node lists longer than 64/128 entries run in the 128/400-slot kernels."""
+    arrays, sg, reads, om, _ = _setup(oracle, genome_len=500, n_reads=3, seed=13, read_len=40)
+    gm = D.PHMMModel(arrays)
+    N = arrays.n_nodes
+    rng = np.random.default_rng(1)
+    for width in (100, 300):
+        pos_off, nodes = [0], []
+        for r in reads:
+            m = om.run(r).to_mapping(min(width, 390))
+            for i in range(len(r)):
+                nodes.extend(m.nodes(i))
+                pos_off.append(len(nodes))
+        mp = (np.array(pos_off, dtype=np.uint64), np.array(nodes, dtype=np.uint32), np.zeros(len(nodes)))
+        rc = D.ReadCollection(reads)
+        tot, lp = gm.to_full_prob_reads(rc, D.Mappings.from_arrays(rc, *mp))
+        olp = om.full_prob_reads(reads, mp, True, n_threads=4)
+        assert np.max(np.abs(lp - olp)) < TOL_LOGP, width
+
+
+def test_mapping_errors(gpu_lib, oracle):
+    arrays, sg, reads, om, mp = _setup(oracle, n_reads=2)
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    bad = mp[1].copy()
+    bad[0] = arrays.n_nodes + 5
+    with pytest.raises(D.PhmmError):
+        gm.to_full_prob_reads(rc, D.Mappings.from_arrays(rc, mp[0], bad, mp[2]))
+    other = D.ReadCollection(reads[:1])
+    with pytest.raises(D.PhmmError):
+        gm.to_full_prob_reads(other, D.Mappings.from_arrays(rc, *mp))
