@@ -344,8 +344,10 @@ int phmm_full_prob_reads(phmm_model *m, const phmm_reads *reads, const phmm_mapp
             check_mapping_nodes(m, mp, reads);
             full_prob_reads_hinted(m, reads, mp, 1, nullptr, nullptr, out_logp, out_total);
         } else {
-            (void)use_max_ratio;
-            PHMM_THROW(PHMM_EINTERNAL, "forward_sparse_score_only without mappings is not built yet");
+            if (!use_max_ratio)
+                PHMM_THROW(PHMM_EINVAL, "use_max_ratio = false (fixed top-k frontier) is not built on the GPU path yet; "
+                                        "the production callers always pass true (multi_dbg/posterior.rs:254)");
+            full_prob_reads_sparse(m, reads, out_logp, out_total, nullptr);
         }
     });
 }
@@ -359,6 +361,22 @@ int phmm_full_prob_reads_candidates(phmm_model *m, const phmm_reads *reads, cons
         if (!init_logp || (m->E && !trans_logp)) PHMM_THROW(PHMM_EINVAL, "NULL candidate arrays");
         check_mapping_nodes(m, mp, reads);
         full_prob_reads_hinted(m, reads, mp, n_cand, init_logp, trans_logp, out_logp, out_total);
+    });
+}
+
+int phmm_generate_mappings(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, int use_max_ratio,
+                           phmm_mappings **out, double *out_node_freq) {
+    return guarded([&] {
+        if (!m || !reads || !out) PHMM_THROW(PHMM_EINVAL, "NULL argument");
+        *out = nullptr;
+        if (reads->R == 0) PHMM_THROW(PHMM_EINVAL, "no reads");
+        if (mp)
+            PHMM_THROW(PHMM_EINVAL, "generate_mappings from existing mappings (run_with_mapping, freq.rs:72-76) is not "
+                                    "built on the GPU path yet; `infer` always passes None (multi_dbg/posterior.rs:735)");
+        if (!use_max_ratio)
+            PHMM_THROW(PHMM_EINVAL, "use_max_ratio = false (fixed top-k frontier) is not built on the GPU path yet; "
+                                    "MultiDbg::generate_mappings always passes true (multi_dbg/posterior.rs:619)");
+        generate_mappings_sparse(m, reads, out, out_node_freq);
     });
 }
 

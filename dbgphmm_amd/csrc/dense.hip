@@ -29,46 +29,10 @@
 #include <cstring>
 #include <numeric>
 
-#include "phmm_internal.h"
+#include "dense_internal.h"
 
 namespace phmm {
 
-static constexpr double LN2 = 0.693147180559945309417232121458;
-static constexpr int BLOCK = 256;
-
-struct DenseArgs {
-    int N, ng, Lc, nblk, npt;
-    // model
-    const uint8_t *emis;
-    const double *init, *dinit, *tdinit;
-    const uint32_t *fc_off;
-    const FwdEntry *fc;
-    const uint32_t *bc_off;
-    const BwdEntry *bc;
-    LinParams lp;
-    const double *logib;  // [Lc] forward InsBegin chain (log)
-    // read batch
-    const uint8_t *bases;  // [ng][Lc][W]
-    const int *len;        // [ng][W]
-    // forward tables
-    double *Fm, *Fi, *Fd;          // [ng][Lc][N][W]
-    int *FE;                       // [ng][Lc+1][W]
-    unsigned long long *cmaxF;     // [ng][Lc][W]
-    double *epart;                 // [ng][ecols][nblk8][W]
-    int eall;                      // 1: end sum for every column (debug tables)
-    double *logPf;                 // [ng][W]
-    double *logE;                  // [ng][Lc][W] per-column e (debug)
-    // backward tables
-    double *Bm, *Bi, *Bd;          // [ng][bcols][N][W]  (Bd may be null)
-    int bcols;                     // 2 (ping-pong) or Lc
-    int *BE;                       // [ng][Lc+1][W]
-    unsigned long long *cmaxB;     // [ng][Lc][W]
-    double *bpart;                 // [2][ng][nblk8][W][2]
-    double *logmbB, *logibB;       // [ng][Lc+1][W]
-    double *accg;                  // [ng][N]
-    int want_freq;
-    int nblk8;                     // nblk rounded up to a multiple of 8 (grid.x)
-};
 
 __device__ __forceinline__ int xcd_block(int b, int nblk8) {
     // physical block b runs on XCD (b % 8); give each XCD a contiguous node range.
@@ -155,7 +119,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int p
     double *cm_ = a.Fm + ((size_t)g * a.Lc + (pos < a.Lc ? pos : 0)) * NW;
     double *ci_ = a.Fi + ((size_t)g * a.Lc + (pos < a.Lc ? pos : 0)) * NW;
 
-    double vmax = 0.0, esum = 0.0;
+    double vmax = 0.0, esum = 0.0, tmax = 0.0;
     const bool want_e = fin || (a.eall && have_prev);
     if (lb < a.nblk) {
         const int kbase = lb * (a.npt * ROWS) + row;
@@ -191,6 +155,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int p
                 mnew = pe * (lp.p_MM * m1 + lp.p_IM * i1 + lp.p_DM * td + a.init[k] * (lp.p_IM * ibs));
                 inew = lp.p_random * (lp.p_MI * om + lp.p_II * oi + lp.p_DI * dprev);
                 if (want_e) esum += om + oi + dprev;
+                tmax = fmax(tmax, om + oi + dprev);
             }
             if (newcol) {
                 const size_t ik = (size_t)k * W + r;
@@ -207,6 +172,13 @@ __global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int p
     const double bm = block_reduce_rows<W>(vmax, OpMax(), lds);
     if (threadIdx.x < W && newcol && lb < a.nblk)
         atomicMax(&a.cmaxF[((size_t)g * a.Lc + pos) * W + r], (unsigned long long)__double_as_longlong(bm));
+    if (a.tmaxF && pos >= 1) {
+        // column maximum of the per-node totals m+i+d (top_nodes_by_score_ratio, table.rs:134-149),
+        // in the stored column's own exponent
+        const double bt = block_reduce_rows<W>(tmax * isc, OpMax(), lds);
+        if (threadIdx.x < W && have_prev && lb < a.nblk)
+            atomicMax(&a.tmaxF[((size_t)g * a.Lc + (pos - 1)) * W + r], (unsigned long long)__double_as_longlong(bt));
+    }
     if (a.eall || __syncthreads_or(fin)) {
         const double bs = block_reduce_rows<W>(esum, OpAdd(), lds);
         if (threadIdx.x < W && want_e && lb < a.nblk) {
@@ -292,7 +264,14 @@ __global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int p
     const int r = threadIdx.x % W;
     const int row = threadIdx.x / W;
     const int len = a.len[g * W + r];
-    const bool live = pos < len;
+    // dense backward columns of this read: 0 .. bstart (the whole read for dense runs; up to the
+    // dense/sparse switch for backward_by_forward, backward.rs:101-142)
+    // bit 30 of bstart: the read has a sparse tail whose F.tables[len-1] (.) b_init term is
+    // produced by the sparse backward kernel
+    const int braw = a.bstart ? a.bstart[g * W + r] : len - 1;
+    const bool sparse_tail = (braw & (1 << 30)) != 0;
+    const int bstart = braw & ~(1 << 30);
+    const bool live = pos < len && pos <= bstart;
     const bool first = live && pos == len - 1;  // previous table is b_init (backward.rs:197-211)
     const LinParams &lp = a.lp;
     const size_t NW = (size_t)a.N * W;
@@ -319,27 +298,30 @@ __global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int p
     // posterior weights  2^(FE+BE) / P
     double wgt = 0.0, wgt2 = 0.0;
     const double *fm = nullptr, *fi = nullptr, *fd = nullptr, *gm = nullptr, *gi = nullptr, *gd = nullptr;
-    if (a.want_freq && live) {
+    const bool want_post = a.want_freq || a.want_map;
+    if (want_post && live) {
         const double lpf = a.logPf[g * W + r];
         if (lpf > -INFINITY) {
             if (pos >= 1) {
                 const int fe = a.FE[((size_t)g * (a.Lc + 1) + (pos - 1)) * W + r];
                 wgt = exp((double)(fe + Epos) * LN2 - lpf);
             }
-            if (first) {
+            if (first && !sparse_tail) {
                 const int fe = a.FE[((size_t)g * (a.Lc + 1) + pos) * W + r];
                 wgt2 = exp((double)fe * LN2 - lpf) * lp.p_end;
             }
         }
     }
-    if (a.want_freq) {
+    if (want_post) {
         const size_t cprev = ((size_t)g * a.Lc + (pos > 0 ? pos - 1 : 0)) * NW;
         const size_t ccur = ((size_t)g * a.Lc + pos) * NW;
         fm = a.Fm + cprev; fi = a.Fi + cprev; fd = a.Fd + cprev;
         gm = a.Fm + ccur; gi = a.Fi + ccur; gd = a.Fd + ccur;
     }
 
-    double vmax = 0.0, s1 = 0.0, s2 = 0.0;
+    double vmax = 0.0, s1 = 0.0, s2 = 0.0, pmx = 0.0, pmx2 = 0.0;
+    double *Pa = a.want_map ? a.Pa + (size_t)g * NW : nullptr;
+    double *Pb = a.want_map ? a.Pb + (size_t)g * NW : nullptr;
     if (lb < a.nblk) {
         const int kbase = lb * (a.npt * ROWS) + row;
         for (int j = 0; j < a.npt; j++) {
@@ -378,8 +360,20 @@ __global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int p
                 const double in = a.init[v];
                 s1 += in * (lp.p_MM * ev * m0 + lp.p_MD * d);
                 s2 += in * (lp.p_IM * ev * m0 + lp.p_ID * d);
-                if (wgt != 0.0) contrib = wgt * (fm[iv] * m + fi[iv] * i + fd[iv] * d);
-                if (wgt2 != 0.0) contrib += wgt2 * (gm[iv] + gi[iv] + gd[iv]);
+                double c1 = 0.0, c2 = 0.0;
+                if (wgt != 0.0) c1 = wgt * (fm[iv] * m + fi[iv] * i + fd[iv] * d);
+                if (wgt2 != 0.0) c2 = wgt2 * (gm[iv] + gi[iv] + gd[iv]);
+                contrib = c1 + c2;
+                if (a.want_map) {
+                    // emit probs of merged index pos (and of merged index len when `first`):
+                    // kept for post_collect (to_mapping_by_score_ratio, hint.rs:135-142)
+                    Pa[iv] = c1;
+                    pmx = fmax(pmx, c1);
+                    if (first && !sparse_tail) {
+                        Pb[iv] = c2;
+                        pmx2 = fmax(pmx2, c2);
+                    }
+                }
             }
             if (a.want_freq) {
                 const double tot = lanes_sum<W>(contrib);
@@ -390,6 +384,14 @@ __global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int p
     const double bmx = block_reduce_rows<W>(vmax, OpMax(), lds);
     if (threadIdx.x < W && live && lb < a.nblk)
         atomicMax(&a.cmaxB[((size_t)g * a.Lc + pos) * W + r], (unsigned long long)__double_as_longlong(bmx));
+    if (a.want_map) {
+        const double p1 = block_reduce_rows<W>(pmx, OpMax(), lds);
+        if (threadIdx.x < W && live && lb < a.nblk)
+            atomicMax(&a.pmax[((size_t)g * (a.Lc + 1) + pos) * W + r], (unsigned long long)__double_as_longlong(p1));
+        const double p2 = block_reduce_rows<W>(pmx2, OpMax(), lds);
+        if (threadIdx.x < W && first && !sparse_tail && lb < a.nblk)
+            atomicMax(&a.pmax[((size_t)g * (a.Lc + 1) + len) * W + r], (unsigned long long)__double_as_longlong(p2));
+    }
     const double t1 = block_reduce_rows<W>(s1, OpAdd(), lds);
     const double t2 = block_reduce_rows<W>(s2, OpAdd(), lds);
     if (threadIdx.x < W && lb < a.nblk) {
@@ -426,7 +428,6 @@ __global__ void __launch_bounds__(BLOCK) to_log_tables(const double *T, const in
 }
 
 // ------------------------------------------------------------------ host driver
-namespace {
 
 struct Timer {
     hipEvent_t a = nullptr, b = nullptr;
@@ -474,6 +475,42 @@ void launch_chunk(const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
     HIP_CHECK(hipGetLastError());
 }
 
+template <int W> static void launch_fwd_one(const DenseArgs &a, int pos) {
+    hipLaunchKernelGGL(fwd_step<W>, dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
+}
+template <int W> static void launch_fwd_fin(const DenseArgs &a) {
+    hipLaunchKernelGGL(fwd_finish<W>, dim3(a.ng, a.eall ? a.Lc : 1), dim3(BLOCK), 0, current_stream(), a);
+}
+#define PHMM_W_SWITCH(W, CALL)                                  \
+    switch (W) {                                                \
+    case 1: CALL(1); break;                                     \
+    case 2: CALL(2); break;                                     \
+    case 4: CALL(4); break;                                     \
+    case 8: CALL(8); break;                                     \
+    case 16: CALL(16); break;                                   \
+    case 32: CALL(32); break;                                   \
+    case 64: CALL(64); break;                                   \
+    default: PHMM_THROW(PHMM_EINTERNAL, "bad read-group width"); \
+    }
+void launch_fwd_step(int W, const DenseArgs &a, int pos) {
+#define CALL_(w) launch_fwd_one<w>(a, pos)
+    PHMM_W_SWITCH(W, CALL_)
+#undef CALL_
+}
+template <int W> static void launch_bwd_one(const DenseArgs &a, int pos) {
+    hipLaunchKernelGGL(bwd_step<W>, dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
+}
+void launch_bwd_step(int W, const DenseArgs &a, int pos) {
+#define CALL_(w) launch_bwd_one<w>(a, pos)
+    PHMM_W_SWITCH(W, CALL_)
+#undef CALL_
+}
+void launch_fwd_finish(int W, const DenseArgs &a) {
+#define CALL_(w) launch_fwd_fin<w>(a)
+    PHMM_W_SWITCH(W, CALL_)
+#undef CALL_
+}
+
 void launch_chunk_w(int W, const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
     switch (W) {
     case 1: launch_chunk<1>(a, do_bwd, st, timing); break;
@@ -511,11 +548,6 @@ struct Carver {
     }
 };
 
-struct Plan {
-    int W, ng_total, npt, nblk, nblk8;
-    std::vector<uint32_t> order;  // reads sorted by length, descending
-};
-
 Plan make_plan(const phmm_model *m, const phmm_reads *reads, int forced_w) {
     Plan p;
     const uint64_t R = reads->R;
@@ -535,11 +567,6 @@ Plan make_plan(const phmm_model *m, const phmm_reads *reads, int forced_w) {
     p.nblk8 = (p.nblk + 7) / 8 * 8;
     return p;
 }
-
-struct ChunkBuffers {
-    DenseArgs a;
-    size_t table_bytes, misc_bytes;
-};
 
 // lay out one chunk (ngc groups, Lc columns); pass null bases to measure
 void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &tb, size_t &mb) {
@@ -567,6 +594,8 @@ void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &
     a.logibB = s.take<double>((size_t)a.ng * (a.Lc + 1) * W);
     a.accg = s.take<double>((size_t)a.ng * a.N);
     a.logib = s.take<double>((size_t)a.Lc + 1);
+    a.tmaxF = s.take<unsigned long long>((size_t)a.ng * a.Lc * W);
+    a.pmax = s.take<unsigned long long>((size_t)a.ng * (a.Lc + 1) * W);
     mb = s.off;
 }
 
@@ -595,8 +624,6 @@ void host_logib(const phmm_model *m, size_t n, std::vector<double> &out) {
         ib = p.p_random + p.p_II + ib;
     }
 }
-
-}  // namespace
 
 void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, uint64_t R,
                     const Plan &plan, bool full_b, bool eall, bool want_b, bool want_freq,
@@ -640,6 +667,7 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
         m->ws_tables.reserve(tb);
         m->ws_misc.reserve(mb);
         layout(a, W, full_b, m->ws_tables.p, m->ws_misc.p, tb, mb);
+        a.tmaxF = nullptr;  // only the adaptive sparse warm-up needs the per-column totals maximum
         HIP_CHECK(hipMemsetAsync(m->ws_misc.p, 0, mb, s));
 
         // host staging: transposed bases, lengths, logib

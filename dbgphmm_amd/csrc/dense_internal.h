@@ -1,0 +1,68 @@
+// Shared between dense.hip (kernels + dense driver) and sparse_dyn.hip (dense warm-up of the
+// adaptive sparse forward).
+#pragma once
+
+#include <vector>
+
+#include "phmm_internal.h"
+
+namespace phmm {
+
+static constexpr double LN2 = 0.693147180559945309417232121458;
+static constexpr int BLOCK = 256;
+
+struct DenseArgs {
+    int N, ng, Lc, nblk, npt;
+    // model
+    const uint8_t *emis;
+    const double *init, *dinit, *tdinit;
+    const uint32_t *fc_off;
+    const FwdEntry *fc;
+    const uint32_t *bc_off;
+    const BwdEntry *bc;
+    LinParams lp;
+    const double *logib;  // [Lc] forward InsBegin chain (log)
+    // read batch
+    const uint8_t *bases;  // [ng][Lc][W]
+    const int *len;        // [ng][W]
+    // forward tables
+    double *Fm, *Fi, *Fd;          // [ng][Lc][N][W]
+    int *FE;                       // [ng][Lc+1][W]
+    unsigned long long *cmaxF;     // [ng][Lc][W]
+    double *epart;                 // [ng][ecols][nblk8][W]
+    int eall;                      // 1: end sum for every column (debug tables)
+    double *logPf;                 // [ng][W]
+    double *logE;                  // [ng][Lc][W] per-column e (debug)
+    // backward tables
+    double *Bm, *Bi, *Bd;          // [ng][bcols][N][W]  (Bd may be null)
+    int bcols;                     // 2 (ping-pong) or Lc
+    int *BE;                       // [ng][Lc+1][W]
+    unsigned long long *cmaxB;     // [ng][Lc][W]
+    double *bpart;                 // [2][ng][nblk8][W][2]
+    double *logmbB, *logibB;       // [ng][Lc+1][W]
+    double *accg;                  // [ng][N]
+    int want_freq;
+    int nblk8;                     // nblk rounded up to a multiple of 8 (grid.x)
+    unsigned long long *tmaxF;     // [ng][Lc][W] max over nodes of m+i+d per column (null: off)
+    // backward_by_forward / mapping extraction (sparse_dyn.hip)
+    const int *bstart;             // [ng][W] last dense backward column of each read (null: len-1)
+    int want_map;                  // keep the per-node emit probs of the column in Pa/Pb
+    double *Pa, *Pb;               // [ng][N][W] emit probs of merged index pos / len
+    unsigned long long *pmax;      // [ng][Lc+1][W] their maxima, by merged index
+};
+
+
+struct Plan {
+    int W, ng_total, npt, nblk, nblk8;
+    std::vector<uint32_t> order;  // reads sorted by length, descending
+};
+
+Plan make_plan(const phmm_model *m, const phmm_reads *reads, int forced_w);
+void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &tb, size_t &mb);
+void fill_model_args(DenseArgs &a, const phmm_model *m);
+void host_logib(const phmm_model *m, size_t n, std::vector<double> &out);
+void launch_fwd_step(int W, const DenseArgs &a, int pos);
+void launch_fwd_finish(int W, const DenseArgs &a);
+void launch_bwd_step(int W, const DenseArgs &a, int pos);
+
+}  // namespace phmm

@@ -1,0 +1,554 @@
+// generate_mappings without input mappings (src/hmmv2/hint.rs:193-220):
+//   run_sparse_adaptive (freq.rs:60-68) = forward_sparse (sparse_dyn.hip) +
+//   backward_by_forward (backward.rs:101-142), then
+//   to_mapping_by_score_ratio (hint.rs:135-142): for every read position the nodes of
+//   S = F (.) B / P (table.rs:500-505) within `active_node_max_ratio` of the best, sorted.
+//
+// Split of the work
+//   * sparse tail of a read (positions >= its dense/sparse switch s0): one wave64 per read,
+//     B columns over filled_nodes(F.tables[i-1]) (table.rs:117-123), frontier in LDS;
+//   * dense head (positions < s0, and whole reads that never left the warm-up): the batched
+//     dense backward kernel (dense.hip) with the emit probs of a column kept in a side
+//     buffer, post_collect gathers the nodes inside the ratio, emit_dense_map sorts them.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "sparse_dyn.h"
+
+namespace phmm {
+
+static constexpr int KMAX = PHMM_MAX_ACTIVE_NODES;
+
+// lighter than FVec: a loaded forward-table record
+template <int CAP> struct FRec {
+    double m[CAP], i[CAP], d[CAP];
+    uint32_t id[CAP];
+    int n, na, E;
+};
+
+template <int CAP> __device__ bool load_record(const RecPool &p, uint64_t pos_index, FRec<CAP> &f) {
+    const uint64_t o1 = p.off[pos_index];
+    if (o1 == 0) return false;
+    const uint8_t *rec = p.base + (o1 - 8);
+    const int *hw = (const int *)rec;
+    const int n = hw[0], na = hw[1], E = hw[2];
+    if (threadIdx.x == 0) {
+        f.n = n;
+        f.na = na;
+        f.E = E;
+    }
+    const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
+    const uint32_t *ids = (const uint32_t *)(rec + 16);
+    const double *m = (const double *)(rec + 16 + idb), *i = m + na, *d = i + na;
+    for (int j = threadIdx.x; j < n; j += 64) {
+        f.id[j] = ids[j];
+        f.d[j] = d[j];
+        f.m[j] = j < na ? m[j] : 0.0;
+        f.i[j] = j < na ? i[j] : 0.0;
+    }
+    __syncthreads();
+    return true;
+}
+
+// to_mapping_by_score_ratio for one position (table.rs:134-149, 163-169): sort val desc
+// (stable in slot order, or by node id when by_node), keep while ln p0 - ln p < ratio,
+// write [n][pad] ids logp.  Returns false if the pool is full.
+template <int CAP>
+__device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32_t *ids, const double *val, int n,
+                             double ratio_lin, bool by_node, uint16_t *order) {
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const double v = val[j];
+        const uint32_t id = ids[j];
+        int rank = 0;
+        for (int q = 0; q < n; q++) {
+            const double u = val[q];
+            rank += (u > v) || (u == v && (by_node ? ids[q] < id : q < j));
+        }
+        order[rank] = (uint16_t)j;
+    }
+    __syncthreads();
+    int keep = 0;
+    if (n > 0) {
+        const double p0 = val[order[0]];
+        int c = 0;
+        for (int j = threadIdx.x; j < n; j += 64) c += (val[j] > 0.0 && val[j] > p0 * ratio_lin) ? 1 : 0;
+        keep = wave_isum(c);
+    }
+    const uint64_t idb = (uint64_t)((keep + 1) & ~1) * 4;
+    const uint64_t bytes = 8 + idb + (uint64_t)keep * 8;
+    const uint64_t o = pool_alloc(mp, bytes);
+    if (o + bytes > mp.cap) return false;
+    uint8_t *rec = mp.base + o;
+    if (threadIdx.x == 0) {
+        ((uint32_t *)rec)[0] = (uint32_t)keep;
+        ((uint32_t *)rec)[1] = 0;
+        mp.off[pos_index] = o + 8;
+    }
+    uint32_t *oid = (uint32_t *)(rec + 8);
+    double *olp = (double *)(rec + 8 + idb);
+    for (int j = threadIdx.x; j < keep; j += 64) {
+        const int s = order[j];
+        oid[j] = ids[s];
+        olp[j] = log(val[s]);
+    }
+    __syncthreads();
+    return true;
+}
+
+struct SparseBwdArgs {
+    SparseModel M;
+    DenseArgs d;
+    int W, Lb;
+    const int *sw;
+    const uint8_t *bases;
+    RecPool fpool, mpool;
+    const uint64_t *lane_pos0;
+    const uint32_t *lanes;
+    double ratio_lin;
+    uint32_t *err;
+};
+
+template <int CAP>
+__global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs a) {
+    __shared__ FRec<CAP> fr;
+    __shared__ Col<CAP> cols[2];
+    __shared__ double val[CAP], dA[CAP], dB[CAP];
+    __shared__ uint32_t list[CAP];
+    __shared__ uint16_t order[CAP];
+    const int lane = threadIdx.x;
+    const uint32_t gi = a.lanes[blockIdx.x];
+    const int g = (int)(gi / a.W), r = (int)(gi % a.W);
+    const int len = a.d.len[gi];
+    const int s0 = a.sw[gi];
+    const uint64_t p0 = a.lane_pos0[gi];
+    const double logP = a.d.logPf[gi];
+    const LinParams &lp = a.M.lp;
+    uint32_t err = 0;
+    const bool ok = logP > -INFINITY;
+    // merged index len: F.tables[len-1] (.) b_init / P   (table.rs:414-434, backward.rs:197-211)
+    if (!load_record<CAP>(a.fpool, p0 + (uint64_t)(len - 1), fr)) err |= SP_ERR_POOL;
+    if (!err) {
+        const double w = ok ? exp((double)fr.E * SP_LN2 - logP) * lp.p_end : 0.0;
+        for (int j = lane; j < fr.n; j += 64) val[j] = w * (fr.m[j] + fr.i[j] + fr.d[j]);
+        __syncthreads();
+        if (!emit_mapping<CAP>(a.mpool, p0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
+            err |= SP_ERR_POOL;
+    }
+    int have_cols = 0;
+    for (int pos = len - 1; pos >= s0 + 1 && !err; pos--) {
+        // B.tables[pos] over filled_nodes(F.tables[pos-1]) (backward.rs:122-129)
+        if (!load_record<CAP>(a.fpool, p0 + (uint64_t)(pos - 1), fr)) {
+            err |= SP_ERR_POOL;
+            break;
+        }
+        for (int j = lane; j < fr.n; j += 64) val[j] = fr.m[j] + fr.i[j] + fr.d[j];
+        __syncthreads();
+        sort_desc<CAP>(val, fr.n, order);
+        __syncthreads();
+        const int nl = fr.na < fr.n ? fr.na : fr.n;
+        for (int j = lane; j < nl; j += 64) list[j] = fr.id[order[j]];
+        __syncthreads();
+        Col<CAP> &prev = cols[(pos + 1) & 1];
+        Col<CAP> &cur = cols[pos & 1];
+        bwd_list_step<CAP>(a.M, prev, pos == len - 1, cur, list, nl, a.bases[((size_t)g * a.Lb + pos) * a.W + r], dA, dB);
+        have_cols = 1;
+        // S = F.tables[pos-1] (.) B.tables[pos] / P over F's elements (table.rs:320-345, 500-505)
+        const double w = ok ? exp((double)(fr.E + cur.E) * SP_LN2 - logP) : 0.0;
+        for (int j = lane; j < fr.n; j += 64) {
+            const int bs = hash_find(cur, fr.id[j]);
+            val[j] = bs >= 0 ? w * (fr.m[j] * cur.m[bs] + fr.i[j] * cur.i[bs] + fr.d[j] * cur.d[bs]) : 0.0;
+        }
+        __syncthreads();
+        if (!emit_mapping<CAP>(a.mpool, p0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
+            err |= SP_ERR_POOL;
+    }
+    // hand B.tables[s0+1] to the dense backward kernel: dense column (zeros elsewhere = the
+    // SparseVec default), its exponent and maximum
+    if (!err && have_cols) {
+        const Col<CAP> &c = cols[(s0 + 1) & 1];
+        const size_t NW = (size_t)a.d.N * a.W;
+        const int pc = (s0 + 1) & 1;
+        double *bm = a.d.Bm + ((size_t)g * a.d.bcols + pc) * NW;
+        double *bi = a.d.Bi + ((size_t)g * a.d.bcols + pc) * NW;
+        for (int k = lane; k < a.d.N; k += 64) {
+            bm[(size_t)k * a.W + r] = 0.0;
+            bi[(size_t)k * a.W + r] = 0.0;
+        }
+        __threadfence();
+        __syncthreads();
+        double mx = 0.0;
+        for (int j = lane; j < c.n; j += 64) {
+            bm[(size_t)c.id[j] * a.W + r] = c.m[j];
+            bi[(size_t)c.id[j] * a.W + r] = c.i[j];
+            mx = fmax(mx, fmax(c.m[j], c.i[j]));
+        }
+        mx = wave_max(mx);
+        if (lane == 0) {
+            a.d.cmaxB[((size_t)g * a.d.Lc + (s0 + 1)) * a.W + r] = (unsigned long long)__double_as_longlong(mx);
+            a.d.BE[((size_t)g * (a.d.Lc + 1) + (s0 + 1)) * a.W + r] = c.E;
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
+    if (lane == 0) a.err[gi] = err;
+}
+
+// ---------------------------------------------------------------- dense head
+struct DenseMapArgs {
+    DenseArgs d;
+    int W;
+    RecPool mpool;
+    const uint64_t *lane_pos0;
+    int *cntA, *cntB;           // [lanes]
+    uint32_t *candA_node, *candB_node;  // [lanes][400]
+    double *candA_val, *candB_val;
+    double ratio_lin;
+    uint32_t *err;
+};
+
+template <int W>
+__global__ void __launch_bounds__(BLOCK) post_collect(const DenseMapArgs ma, const int pos) {
+    const DenseArgs &a = ma.d;
+    const int g = blockIdx.y, lb = blockIdx.x;
+    constexpr int ROWS = BLOCK / W;
+    const int r = threadIdx.x % W, row = threadIdx.x / W;
+    const int gi = g * W + r;
+    const int len = a.len[gi];
+    const int braw = a.bstart[gi];
+    const bool sparse_tail = (braw & (1 << 30)) != 0;
+    const int bstart = braw & ~(1 << 30);
+    const bool live = pos < len && pos <= bstart;
+    const bool doA = live && pos >= 1;
+    const bool doB = live && pos == len - 1 && !sparse_tail;
+    if (lb >= a.nblk) return;
+    const size_t NW = (size_t)a.N * W;
+    const int kbase = lb * (a.npt * ROWS) + row;
+    for (int which = 0; which < 2; which++) {
+        if (!(which == 0 ? doA : doB)) continue;
+        const double *P = (which == 0 ? a.Pa : a.Pb) + (size_t)g * NW;
+        const int mi = which == 0 ? pos : len;
+        const double thr =
+            __longlong_as_double((long long)a.pmax[((size_t)g * (a.Lc + 1) + mi) * W + r]) * ma.ratio_lin;
+        int *cnt = which == 0 ? ma.cntA : ma.cntB;
+        uint32_t *cn = (which == 0 ? ma.candA_node : ma.candB_node) + (size_t)gi * KMAX;
+        double *cv = (which == 0 ? ma.candA_val : ma.candB_val) + (size_t)gi * KMAX;
+        int local = 0;
+        for (int j = 0; j < a.npt; j++) {
+            const int k = kbase + j * ROWS;
+            if (k >= a.N) break;
+            const double t = P[(size_t)k * W + r];
+            local += (t > 0.0 && t > thr) ? 1 : 0;
+        }
+        if (local == 0) continue;
+        int slot = atomicAdd(&cnt[gi], local);
+        for (int j = 0; j < a.npt && slot < KMAX; j++) {
+            const int k = kbase + j * ROWS;
+            if (k >= a.N) break;
+            const double t = P[(size_t)k * W + r];
+            if (t > 0.0 && t > thr) {
+                cn[slot] = (uint32_t)k;
+                cv[slot] = t;
+                slot++;
+            }
+        }
+    }
+}
+
+// More than 400 nodes inside the ratio: keep the 400 best of the column (ties: lowest node id).
+__device__ int wave_top_from_column(const double *col, int stride, int N, double thr, double vmax, uint32_t *ids,
+                                    double *val) {
+    const int lane = threadIdx.x;
+    unsigned long long lo = (unsigned long long)__double_as_longlong(thr), hi = (unsigned long long)__double_as_longlong(vmax);
+    while (lo < hi) {  // largest T with count(v >= T) >= KMAX
+        const unsigned long long mid = lo + (hi - lo + 1ull) / 2ull;
+        int c = 0;
+        for (int k = lane; k < N; k += 64) {
+            const double v = col[(size_t)k * stride];
+            c += (v > thr && (unsigned long long)__double_as_longlong(v) >= mid) ? 1 : 0;
+        }
+        c = wave_isum(c);
+        if (c >= KMAX) lo = mid;
+        else hi = mid - 1ull;
+    }
+    const unsigned long long T = lo;
+    int n = 0;
+    // first everything above T, then ties in node order until the list is full
+    for (int pass = 0; pass < 2; pass++)
+        for (int base = 0; base < N && n < KMAX; base += 64) {
+            const int k = base + lane;
+            double v = 0.0;
+            bool take = false;
+            if (k < N) {
+                v = col[(size_t)k * stride];
+                const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+                take = v > thr && (pass == 0 ? b > T : b == T);
+            }
+            const unsigned long long mk = __ballot(take);
+            const int p = n + __popcll(mk & ((1ull << lane) - 1ull));
+            if (take && p < KMAX) {
+                ids[p] = (uint32_t)k;
+                val[p] = v;
+            }
+            n += __popcll(mk);
+        }
+    __syncthreads();
+    return n < KMAX ? n : KMAX;
+}
+
+// one wave per (lane, which): sort the collected nodes and write the mapping record
+__global__ void __launch_bounds__(64) emit_dense_map(const DenseMapArgs ma, const int pos) {
+    __shared__ uint32_t ids[KMAX];
+    __shared__ double val[KMAX];
+    __shared__ uint16_t order[KMAX];
+    const DenseArgs &a = ma.d;
+    const int gi = blockIdx.x, which = blockIdx.y;
+    const int len = a.len[gi];
+    if (len == 0) return;
+    const int braw = a.bstart[gi];
+    const bool sparse_tail = (braw & (1 << 30)) != 0;
+    const int bstart = braw & ~(1 << 30);
+    const bool live = pos < len && pos <= bstart;
+    const bool mine = which == 0 ? (live && pos >= 1) : (live && pos == len - 1 && !sparse_tail);
+    if (!mine) return;
+    int *cnt = which == 0 ? ma.cntA : ma.cntB;
+    const int c = cnt[gi];
+    const int g = gi / ma.W, r = gi % ma.W;
+    const int mi = which == 0 ? pos : len;
+    int n = c < KMAX ? c : KMAX;
+    if (c > KMAX) {
+        const double *P = (which == 0 ? a.Pa : a.Pb) + (size_t)g * a.N * ma.W + r;
+        const double vmax = __longlong_as_double((long long)a.pmax[((size_t)g * (a.Lc + 1) + mi) * ma.W + r]);
+        n = wave_top_from_column(P, ma.W, a.N, vmax * ma.ratio_lin, vmax, ids, val);
+    } else {
+        const uint32_t *cn = (which == 0 ? ma.candA_node : ma.candB_node) + (size_t)gi * KMAX;
+        const double *cv = (which == 0 ? ma.candA_val : ma.candB_val) + (size_t)gi * KMAX;
+        for (int j = threadIdx.x; j < n; j += 64) {
+            ids[j] = cn[j];
+            val[j] = cv[j];
+        }
+    }
+    __syncthreads();
+    const uint64_t pidx = ma.lane_pos0[gi] + (uint64_t)(mi - 1);
+    if (!emit_mapping<KMAX>(ma.mpool, pidx, ids, val, n, ma.ratio_lin, true, order)) {
+        if (threadIdx.x == 0) atomicOr(&ma.err[gi], SP_ERR_POOL);
+    }
+    if (threadIdx.x == 0) cnt[gi] = 0;
+}
+
+__global__ void __launch_bounds__(BLOCK) merge_logp(const uint32_t *lanes, int n, const double *src, double *dst) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j < n) dst[lanes[j]] = src[lanes[j]];
+}
+
+namespace {
+template <int W> void launch_post_collect(const DenseMapArgs &ma, int pos) {
+    hipLaunchKernelGGL(post_collect<W>, dim3(ma.d.nblk, ma.d.ng), dim3(BLOCK), 0, current_stream(), ma, pos);
+}
+void launch_post_collect_w(int W, const DenseMapArgs &ma, int pos) {
+    switch (W) {
+    case 1: launch_post_collect<1>(ma, pos); break;
+    case 2: launch_post_collect<2>(ma, pos); break;
+    case 4: launch_post_collect<4>(ma, pos); break;
+    case 8: launch_post_collect<8>(ma, pos); break;
+    case 16: launch_post_collect<16>(ma, pos); break;
+    case 32: launch_post_collect<32>(ma, pos); break;
+    case 64: launch_post_collect<64>(ma, pos); break;
+    default: PHMM_THROW(PHMM_EINTERNAL, "bad read-group width");
+    }
+}
+}  // namespace
+
+void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_lanes, MappingSink *sink,
+                            const Plan &plan, int g0, uint64_t R) {
+    hipStream_t s = current_stream();
+    CallStats &st = stats();
+    phmm_model *m = mc.m;
+    const int W = mc.W, lanes = mc.lanes;
+    const std::vector<int> &hl = *mc.hl, &hsw = *mc.hsw;
+    const std::vector<uint64_t> &lp0 = *mc.lane_pos0;
+    const uint64_t n_pos = lp0[lanes];
+    const size_t NW = (size_t)m->N * W;
+
+    // per-lane control
+    std::vector<int> hb(lanes, 0);
+    int pos_max = -1;
+    for (int gi = 0; gi < lanes; gi++) {
+        if (hl[gi] == 0) {
+            hb[gi] = -1;
+            continue;
+        }
+        if (hsw[gi] < hl[gi]) hb[gi] = hsw[gi] | (1 << 30);
+        else hb[gi] = hl[gi] - 1;
+        pos_max = std::max(pos_max, hb[gi] & ~(1 << 30));
+    }
+    DevBuf ctl, pbuf, mpool, mmeta;
+    size_t cb = 0;
+    auto carve = [&](size_t bytes) {
+        cb = (cb + 255) / 256 * 256;
+        size_t o = cb;
+        cb += bytes;
+        return o;
+    };
+    const size_t o_bs = carve(sizeof(int) * lanes), o_ca = carve(sizeof(int) * lanes), o_cb = carve(sizeof(int) * lanes),
+                 o_err = carve(sizeof(uint32_t) * lanes), o_lanes = carve(sizeof(uint32_t) * std::max<size_t>(sparse_lanes.size(), 1)),
+                 o_lp0 = carve(sizeof(uint64_t) * (lanes + 1)),
+                 o_bn = carve(sizeof(uint32_t) * (size_t)lanes * KMAX), o_bv = carve(sizeof(double) * (size_t)lanes * KMAX);
+    ctl.reserve(cb);
+    char *cp = (char *)ctl.p;
+    pbuf.reserve(2 * (size_t)mc.ngc * NW * sizeof(double));
+    uint64_t map_cap = n_pos * 256 + (1u << 20);
+
+    for (int attempt = 0;; attempt++) {
+        HIP_CHECK(hipMemsetAsync(cp, 0, cb, s));
+        HIP_CHECK(hipMemcpyAsync(cp + o_bs, hb.data(), sizeof(int) * lanes, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(cp + o_lp0, lp0.data(), sizeof(uint64_t) * (lanes + 1), hipMemcpyHostToDevice, s));
+        if (!sparse_lanes.empty())
+            HIP_CHECK(hipMemcpyAsync(cp + o_lanes, sparse_lanes.data(), sizeof(uint32_t) * sparse_lanes.size(),
+                                     hipMemcpyHostToDevice, s));
+        mpool.reserve(map_cap);
+        mmeta.reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1));
+        HIP_CHECK(hipMemsetAsync(mmeta.p, 0, mmeta.bytes, s));
+        RecPool mp{};
+        mp.base = mpool.as<uint8_t>();
+        mp.cap = map_cap;
+        mp.top = mmeta.as<unsigned long long>();
+        mp.off = (uint64_t *)(mmeta.as<char>() + 8);
+
+        DenseArgs a = mc.a;
+        a.want_freq = 0;
+        a.want_map = 1;
+        a.bstart = (const int *)(cp + o_bs);
+        a.Pa = pbuf.as<double>();
+        a.Pb = pbuf.as<double>() + (size_t)mc.ngc * NW;
+        // backward scratch of the chunk must start clean (a previous attempt may have used it)
+        HIP_CHECK(hipMemsetAsync(a.cmaxB, 0, sizeof(unsigned long long) * (size_t)a.ng * a.Lc * W, s));
+        HIP_CHECK(hipMemsetAsync(a.pmax, 0, sizeof(unsigned long long) * (size_t)a.ng * (a.Lc + 1) * W, s));
+        HIP_CHECK(hipMemsetAsync(a.BE, 0, sizeof(int) * (size_t)a.ng * (a.Lc + 1) * W, s));
+
+        if (!sparse_lanes.empty()) {
+            // ln P of the sparse reads joins the dense ones (posterior weights)
+            hipLaunchKernelGGL(merge_logp, dim3((unsigned)((sparse_lanes.size() + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                               (const uint32_t *)(cp + o_lanes), (int)sparse_lanes.size(), mc.d_logp_sparse, a.logPf);
+            SparseBwdArgs ba{};
+            ba.M = mc.fa_M;
+            ba.d = a;
+            ba.W = W;
+            ba.Lb = mc.Lfull;
+            ba.sw = mc.d_sw;
+            ba.bases = mc.d_bases_full;
+            ba.fpool = mc.fpool;
+            ba.mpool = mp;
+            ba.lane_pos0 = (const uint64_t *)(cp + o_lp0);
+            ba.lanes = (const uint32_t *)(cp + o_lanes);
+            ba.ratio_lin = mc.ratio_lin;
+            ba.err = (uint32_t *)(cp + o_err);
+            hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)sparse_lanes.size()), dim3(64), 0, s, ba);
+            HIP_CHECK(hipGetLastError());
+            st.launches[3]++;
+        }
+        DenseMapArgs ma{};
+        ma.d = a;
+        ma.W = W;
+        ma.mpool = mp;
+        ma.lane_pos0 = (const uint64_t *)(cp + o_lp0);
+        ma.cntA = (int *)(cp + o_ca);
+        ma.cntB = (int *)(cp + o_cb);
+        ma.candA_node = mc.cand_node;
+        ma.candA_val = mc.cand_tot;
+        ma.candB_node = (uint32_t *)(cp + o_bn);
+        ma.candB_val = (double *)(cp + o_bv);
+        ma.ratio_lin = mc.ratio_lin;
+        ma.err = (uint32_t *)(cp + o_err);
+        for (int pos = pos_max; pos >= 0; pos--) {
+            launch_bwd_step(W, a, pos);
+            launch_post_collect_w(W, ma, pos);
+            hipLaunchKernelGGL(emit_dense_map, dim3(lanes, 2), dim3(64), 0, s, ma, pos);
+            st.launches[1]++;
+        }
+        HIP_CHECK(hipGetLastError());
+        std::vector<uint32_t> herr(lanes);
+        HIP_CHECK(hipMemcpyAsync(herr.data(), cp + o_err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        bool pool_full = false;
+        for (int gi = 0; gi < lanes; gi++) {
+            if (herr[gi] & SP_ERR_POOL) pool_full = true;
+            else if (herr[gi]) PHMM_THROW(PHMM_EINTERNAL, "mapping backward error " + std::to_string(herr[gi]));
+        }
+        if (!pool_full) {
+            // gather the records
+            unsigned long long used = 0;
+            HIP_CHECK(hipMemcpy(&used, mp.top, sizeof(used), hipMemcpyDeviceToHost));
+            std::vector<uint8_t> hp(used);
+            std::vector<uint64_t> hoff(n_pos);
+            if (used) HIP_CHECK(hipMemcpy(hp.data(), mp.base, used, hipMemcpyDeviceToHost));
+            if (n_pos) HIP_CHECK(hipMemcpy(hoff.data(), mp.off, sizeof(uint64_t) * n_pos, hipMemcpyDeviceToHost));
+            for (int gi = 0; gi < lanes; gi++) {
+                const size_t slot = (size_t)g0 * W + gi;
+                if (slot >= R || hl[gi] == 0) continue;
+                const uint32_t rd = plan.order[slot];
+                auto &cnt = sink->count[rd];
+                auto &nd = sink->nodes[rd];
+                auto &lg = sink->logp[rd];
+                cnt.assign(hl[gi], 0);
+                for (int i = 0; i < hl[gi]; i++) {
+                    const uint64_t o1 = hoff[lp0[gi] + i];
+                    if (!o1) continue;
+                    const uint8_t *rec = hp.data() + (o1 - 8);
+                    const uint32_t n = ((const uint32_t *)rec)[0];
+                    const uint64_t idb = (uint64_t)((n + 1) & ~1u) * 4;
+                    const uint32_t *ids = (const uint32_t *)(rec + 8);
+                    const double *lps = (const double *)(rec + 8 + idb);
+                    cnt[i] = n;
+                    nd.insert(nd.end(), ids, ids + n);
+                    lg.insert(lg.end(), lps, lps + n);
+                }
+            }
+            break;
+        }
+        if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "mapping pool keeps overflowing");
+        map_cap *= 2;
+    }
+}
+
+// PHMMModel::generate_mappings(reads, None, use_max_ratio = true)
+void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq) {
+    MappingSink sink;
+    sink.count.resize(reads->R);
+    sink.nodes.resize(reads->R);
+    sink.logp.resize(reads->R);
+    std::vector<double> lf(reads->R);
+    double tot = 0.0;
+    full_prob_reads_sparse(m, reads, lf.data(), &tot, &sink);
+    auto *mp = new phmm_mappings();
+    mp->R = reads->R;
+    mp->total_pos = reads->total;
+    mp->read_off = reads->off;
+    mp->pos_off.assign(reads->total + 1, 0);
+    mp->read_max_list.assign(reads->R, 0);
+    uint64_t w = 0;
+    for (uint64_t r = 0; r < reads->R; r++) {
+        const uint64_t len = reads->off[r + 1] - reads->off[r];
+        for (uint64_t i = 0; i < len; i++) {
+            const uint32_t c = i < sink.count[r].size() ? sink.count[r][i] : 0;
+            w += c;
+            mp->pos_off[reads->off[r] + i + 1] = w;
+            mp->read_max_list[r] = std::max(mp->read_max_list[r], c);
+        }
+        mp->nodes.insert(mp->nodes.end(), sink.nodes[r].begin(), sink.nodes[r].end());
+        mp->logp.insert(mp->logp.end(), sink.logp[r].begin(), sink.logp[r].end());
+    }
+    if (out_node_freq) {
+        // Mappings::to_node_freqs (hint.rs:161-171)
+        std::vector<double> f(m->N, 0.0);
+        for (size_t a = 0; a < mp->nodes.size(); a++) f[mp->nodes[a]] += std::exp(mp->logp[a]);
+        try {
+            put_doubles(out_node_freq, f.data(), m->N);
+        } catch (...) {
+            delete mp;
+            throw;
+        }
+    }
+    *out = mp;
+}
+
+}  // namespace phmm

@@ -165,6 +165,10 @@ void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *o
 void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
                             const double *init_logp, const double *trans_logp, double *out_logp,
                             double *out_total);
+struct MappingSink;
+void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total,
+                            MappingSink *sink);
+void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq);
 void ensure_logib(phmm_model *m, size_t len);
 void put_doubles(double *dst, const double *src_host, size_t n);
 void dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i,

@@ -244,7 +244,3 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
 
 }  // namespace phmm
 
-extern "C" int phmm_generate_mappings(phmm_model *, const phmm_reads *, const phmm_mappings *, int, phmm_mappings **,
-                                      double *) {
-    return phmm::fail(PHMM_EINTERNAL, "not built yet");
-}

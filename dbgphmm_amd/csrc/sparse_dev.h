@@ -226,6 +226,104 @@ __device__ uint32_t fwd_list_step(const SparseModel &M, const Col<CAP> &prev, Co
     return err;
 }
 
+// ---------------------------------------------------------------------------------
+// One backward column over a GIVEN node list (non-adaptive b_step, backward.rs:216-261 with
+// is_adaptive = false: backward_with_mapping / backward_by_forward, backward.rs:59-142):
+//   bd = bd0 + G x bdt restricted to the list (299-404), bm (423-444), bi (462-483);
+//   the begin states bmb/bib are not needed by the mapping flow and are left out.
+// prev: the column of position pos+1; prev_is_init: it is b_init (m = i = d = p_end for every
+// node, backward.rs:197-211).  list may live in LDS or global memory.
+template <int CAP>
+__device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool prev_is_init, Col<CAP> &cur,
+                              const uint32_t *list, int n, uint8_t x, double *dA, double *dB) {
+    const LinParams &lp = M.lp;
+    hash_clear(cur);
+    if (threadIdx.x == 0) {
+        cur.n = n;
+        cur.na = n;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const uint32_t k = list[j];
+        cur.id[j] = k;
+        hash_insert(cur, k, j);
+    }
+    __syncthreads();
+    const double pend = lp.p_end;
+    // bd0 (backward.rs:354-377); keep A1 = sum_w t e_w m'[w] and q0 = p_r i'[v] for bm/bi
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const uint32_t v = cur.id[j];
+        double a1 = 0.0;
+        for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
+            const double w = M.trans[M.chi_edge[a]];
+            if (w == 0.0) continue;
+            const uint32_t u = M.chi_node[a];
+            double mu = 0.0;
+            if (prev_is_init) mu = pend;
+            else {
+                const int ps = hash_find(prev, u);
+                if (ps >= 0) mu = prev.m[ps];
+            }
+            a1 += w * (M.emis[u] == x ? lp.p_match : lp.p_mismatch) * mu;
+        }
+        double iv = 0.0;
+        if (prev_is_init) iv = pend;
+        else {
+            const int os = hash_find(prev, v);
+            if (os >= 0) iv = prev.i[os];
+        }
+        const double q0 = lp.p_random * iv;
+        const double d0 = lp.p_DM * a1 + lp.p_DI * q0;
+        cur.m[j] = a1;  // stash
+        cur.i[j] = q0;  // stash
+        cur.d[j] = d0;
+        dA[j] = d0;
+    }
+    __syncthreads();
+    // bdt (backward.rs:387-404), restricted to the list
+    double *src = dA, *dst = dB;
+    for (int t = 1; t <= lp.n_max_gaps; t++) {
+        for (int j = threadIdx.x; j < n; j += 64) {
+            const uint32_t v = cur.id[j];
+            double s = 0.0;
+            for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
+                const double w = M.trans[M.chi_edge[a]];
+                if (w == 0.0) continue;
+                const int cs = hash_find(cur, M.chi_node[a]);
+                if (cs >= 0) s += w * src[cs];
+            }
+            s *= lp.p_DD;
+            dst[j] = s;
+            cur.d[j] += s;
+        }
+        __syncthreads();
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    // bm, bi: sum_w t (p_XM e_w m'[w] + p_XD d[w]) + p_XI p_r i'[v]
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const uint32_t v = cur.id[j];
+        double td = 0.0;
+        for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
+            const double w = M.trans[M.chi_edge[a]];
+            if (w == 0.0) continue;
+            const int cs = hash_find(cur, M.chi_node[a]);
+            if (cs >= 0) td += w * cur.d[cs];
+        }
+        dA[j] = td;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const double a1 = cur.m[j], q0 = cur.i[j], td = dA[j];
+        cur.m[j] = lp.p_MM * a1 + lp.p_MD * td + lp.p_MI * q0;
+        cur.i[j] = lp.p_IM * a1 + lp.p_ID * td + lp.p_II * q0;
+    }
+    __syncthreads();
+    col_rescale(cur, prev_is_init ? 0 : prev.E, 0.0);
+    __syncthreads();
+}
+
 // fe (forward.rs:554-558): ln(p_end * sum over the active list of m+i+d) + E ln2
 template <int CAP> __device__ __forceinline__ double col_log_end(const SparseModel &M, const Col<CAP> &c) {
     double s = 0.0;

@@ -1,0 +1,109 @@
+// Shared between sparse_dyn.hip (adaptive sparse forward) and mapping_flow.hip
+// (backward_by_forward + mapping extraction).
+#pragma once
+
+#include "frontier_dev.h"
+
+namespace phmm {
+
+static constexpr uint32_t SP_ERR_POOL = 16u;  // record pool exhausted: the host grows it and reruns
+
+// Bump-allocated records in HBM, one per (read, position).
+//   forward table record : [n u32][na u32][E i32][pad] ids[n|1] m[na] i[na] d[n]
+//   mapping record       : [n u32][pad u32]            ids[n|1] logp[n]
+struct RecPool {
+    uint8_t *base;
+    unsigned long long *top;  // bytes used
+    uint64_t cap;
+    uint64_t *off;  // [positions] byte offset of the record + 8 (0 = none); the bias keeps every derived address 8-byte aligned: hipcc folds a "+1 -1" bias into a misaligned scalar-load base, whose low bits the hardware drops
+};
+
+__device__ __forceinline__ uint64_t pool_alloc(const RecPool &p, uint64_t bytes) {
+    // wave-uniform: lane 0 allocates, everyone gets the offset
+    unsigned long long o = 0;
+    if (threadIdx.x == 0) o = atomicAdd(p.top, (unsigned long long)bytes);
+    o = __shfl(o, 0);
+    return o;
+}
+
+template <int CAP> __device__ bool store_record(const RecPool &p, uint64_t pos_index, const FVec<CAP> &c) {
+    const int n = c.n, na = c.na;
+    const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
+    const uint64_t bytes = 16 + idb + (uint64_t)(2 * na + n) * 8;
+    const uint64_t o = pool_alloc(p, bytes);
+    if (o + bytes > p.cap) return false;
+    uint8_t *rec = p.base + o;
+    if (threadIdx.x == 0) {
+        ((uint32_t *)rec)[0] = (uint32_t)n;
+        ((uint32_t *)rec)[1] = (uint32_t)na;
+        ((int *)rec)[2] = c.E;
+        ((uint32_t *)rec)[3] = 0;
+        p.off[pos_index] = o + 8;
+    }
+    uint32_t *ids = (uint32_t *)(rec + 16);
+    double *m = (double *)(rec + 16 + idb), *i = m + na, *d = i + na;
+    for (int j = threadIdx.x; j < n; j += 64) {
+        ids[j] = c.id[j];
+        d[j] = c.d[j];
+        if (j < na) {
+            m[j] = c.m[j];
+            i[j] = c.i[j];
+        }
+    }
+    return true;
+}
+
+inline SparseModel sparse_model_of(const phmm_model *m) {
+    const ModelDev &d = m->dev;
+    SparseModel s{};
+    s.N = (int)m->N;
+    s.emis = d.emis.as<uint8_t>();
+    s.init = d.init.as<double>();
+    s.par_off = d.par_off.as<uint32_t>();
+    s.par_node = d.par_node.as<uint32_t>();
+    s.par_edge = d.par_edge.as<uint32_t>();
+    s.chi_off = d.chi_off.as<uint32_t>();
+    s.chi_node = d.chi_node.as<uint32_t>();
+    s.chi_edge = d.chi_edge.as<uint32_t>();
+    s.trans = d.trans_lin.as<double>();
+    s.lp = m->lin;
+    s.logib = d.logib.as<double>();
+    return s;
+}
+
+}  // namespace phmm
+
+#include "dense_internal.h"
+
+namespace phmm {
+
+// Host-side collector of the mapping lists of all reads (original read order).
+struct MappingSink {
+    std::vector<std::vector<uint32_t>> count;  // [read][pos]
+    std::vector<std::vector<uint32_t>> nodes;  // [read] concatenated
+    std::vector<std::vector<double>> logp;
+};
+
+// Everything the backward/mapping pass needs to know about one chunk of read groups after
+// its (dense warm-up + sparse) forward pass.
+struct MapChunk {
+    phmm_model *m;
+    int W, Lc, Lfull, ngc, lanes;
+    DenseArgs a;
+    SparseModel fa_M;
+    const int *d_sw;
+    const uint8_t *d_bases_full;
+    RecPool fpool;
+    const uint64_t *d_lane_pos0;
+    const std::vector<int> *hl, *hsw;
+    const std::vector<uint64_t> *lane_pos0;
+    double ratio_lin;
+    double *d_logp_sparse;
+    uint32_t *cand_node;  // [lanes][400] scratch
+    double *cand_tot;
+};
+
+void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_lanes, MappingSink *sink,
+                            const Plan &plan, int g0, uint64_t R);
+
+}  // namespace phmm

@@ -1,0 +1,623 @@
+// Adaptive sparse forward = PHMMModel::forward_sparse / forward_sparse_score_only with
+// use_max_ratio = true (src/hmmv2/forward.rs:93-206):
+//   column 0 dense; column i < n_warmup dense while the previous (dense) column has more
+//   than warmup_threshold nodes within `active_node_max_ratio` of its best node
+//   (table.rs:134-149); afterwards sparse for good: active = to_childs_and_us(top nodes),
+//   f_step(.., is_dense = false, is_adaptive = true).
+//
+// GPU formulation
+//   * the dense warm-up columns of ALL reads of a read group run through the batched dense
+//     kernel (dense.hip) -- that is where the HBM traffic of this mode is;
+//   * col_count counts, per read, the nodes of a dense column within the ratio of the
+//     column's best node and collects them (<= 400) as the first sparse step's top list;
+//   * each read then continues on its own wave64 with the frontier in LDS (frontier_dev.h).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "dense_internal.h"
+#include "frontier_dev.h"
+#include "sparse_dyn.h"
+
+namespace phmm {
+
+struct WarmArgs {
+    DenseArgs d;
+    int *sw;                   // [ng][W] switch position s_r (-1 = undecided)
+    int *cnt;                  // [ng][W] nodes within the ratio in the column being counted
+    uint32_t *cand_node;       // [ng][W][400]
+    double *cand_tot;          // [ng][W][400]
+    int *cand_n;               // [ng][W] candidates kept for the switch column
+    int *undecided;            // [1]
+    double ratio_lin;          // exp(-active_node_max_ratio)
+    int n_warmup, threshold;
+};
+
+// count (and collect) the nodes of dense column `col` with total > tmax * exp(-ratio)
+template <int W>
+__global__ void __launch_bounds__(BLOCK) col_count(const WarmArgs wa, const int col) {
+    const DenseArgs &a = wa.d;
+    const int g = blockIdx.y;
+    const int lb = blockIdx.x;
+    constexpr int ROWS = BLOCK / W;
+    const int r = threadIdx.x % W, row = threadIdx.x / W;
+    const int gi = g * W + r;
+    const int len = a.len[gi];
+    const bool live = wa.sw[gi] < 0 && col < len;
+    if (lb >= a.nblk) return;
+    const size_t NW = (size_t)a.N * W;
+    const double *fm = a.Fm + ((size_t)g * a.Lc + col) * NW;
+    const double *fi = a.Fi + ((size_t)g * a.Lc + col) * NW;
+    const double *fd = a.Fd + ((size_t)g * a.Lc + col) * NW;
+    double thr = 0.0;
+    if (live) {
+        const unsigned long long tb = a.tmaxF[((size_t)g * a.Lc + col) * W + r];
+        thr = __longlong_as_double((long long)tb) * wa.ratio_lin;
+    }
+    const int kbase = lb * (a.npt * ROWS) + row;
+    int local = 0;
+    if (live)
+        for (int j = 0; j < a.npt; j++) {
+            const int k = kbase + j * ROWS;
+            if (k >= a.N) break;
+            const size_t ix = (size_t)k * W + r;
+            const double t = fm[ix] + fi[ix] + fd[ix];
+            local += (t > 0.0 && t > thr) ? 1 : 0;
+        }
+    if (local > 0) {
+        int slot = atomicAdd(&wa.cnt[gi], local);
+        if (slot < PHMM_MAX_ACTIVE_NODES)
+            for (int j = 0; j < a.npt; j++) {
+                const int k = kbase + j * ROWS;
+                if (k >= a.N) break;
+                const size_t ix = (size_t)k * W + r;
+                const double t = fm[ix] + fi[ix] + fd[ix];
+                if (t > 0.0 && t > thr) {
+                    if (slot < PHMM_MAX_ACTIVE_NODES) {
+                        wa.cand_node[(size_t)gi * PHMM_MAX_ACTIVE_NODES + slot] = (uint32_t)k;
+                        wa.cand_tot[(size_t)gi * PHMM_MAX_ACTIVE_NODES + slot] = t;
+                    }
+                    slot++;
+                }
+            }
+    }
+}
+
+// decision for column `pos` from the count of column pos-1 (forward.rs:107-137):
+//   sparse at pos  iff  pos >= n_warmup  or  count(pos-1) <= warmup_threshold
+// a read that ends at pos while still dense is finished (sw = len).
+__global__ void __launch_bounds__(BLOCK) warm_decide(const WarmArgs wa, const int pos, const int total_lanes) {
+    const int gi = blockIdx.x * BLOCK + threadIdx.x;
+    if (gi >= total_lanes) return;
+    const int len = wa.d.len[gi];
+    if (len == 0) {
+        wa.sw[gi] = 0;
+        return;
+    }
+    if (wa.sw[gi] >= 0) return;
+    bool decided = false;
+    if (pos >= len) {
+        wa.sw[gi] = len;  // all columns were dense
+        decided = true;
+    } else if (pos >= 1) {
+        const int c = wa.cnt[gi];
+        const int ntop = c < PHMM_MAX_ACTIVE_NODES ? c : PHMM_MAX_ACTIVE_NODES;  // ArrayVec capacity
+        if (pos >= wa.n_warmup || ntop <= wa.threshold) {
+            wa.sw[gi] = pos;
+            wa.cand_n[gi] = c;
+            decided = true;
+        }
+    }
+    if (!decided) atomicAdd(wa.undecided, 1);
+    wa.cnt[gi] = 0;
+}
+
+// Forced switch (pos >= n_warmup) with more than 400 nodes inside the ratio: the reference's
+// `to_sorted_arrayvec()` keeps the 400 best of the dense nodevec (table.rs:139; ties resolved
+// by node index here).  One block per such read: compact the qualifying (node, total) pairs,
+// bisect the 400th-largest total on its bit pattern, then bisect the node id among ties.
+__device__ __forceinline__ int block_count(int local, int *lds_i) {
+    __syncthreads();
+    if (threadIdx.x == 0) *lds_i = 0;
+    __syncthreads();
+    local = wave_isum(local);
+    if ((threadIdx.x & 63) == 0) atomicAdd(lds_i, local);
+    __syncthreads();
+    return *lds_i;
+}
+
+struct Top400Args {
+    DenseArgs d;
+    int W;
+    const int *sw;
+    const uint32_t *need;  // lanes (g*W + r) that need the selection
+    uint32_t *sc_node;     // [n_need][N]
+    double *sc_tot;        // [n_need][N]
+    int *sc_n;             // [n_need]
+    uint32_t *cand_node;
+    double *cand_tot;
+    int *cand_n;
+    double ratio_lin;
+};
+
+__global__ void __launch_bounds__(BLOCK) select_top400(const Top400Args a) {
+    __shared__ int cnt;
+    const uint32_t gi = a.need[blockIdx.x];
+    const int g = (int)(gi / a.W), r = (int)(gi % a.W);
+    const int col = a.sw[gi] - 1;
+    const int N = a.d.N;
+    const size_t NW = (size_t)N * a.W;
+    const double *fm = a.d.Fm + ((size_t)g * a.d.Lc + col) * NW;
+    const double *fi = a.d.Fi + ((size_t)g * a.d.Lc + col) * NW;
+    const double *fd = a.d.Fd + ((size_t)g * a.d.Lc + col) * NW;
+    const double tmax = __longlong_as_double((long long)a.d.tmaxF[((size_t)g * a.d.Lc + col) * a.W + r]);
+    const double thr = tmax * a.ratio_lin;
+    uint32_t *sn = a.sc_node + (size_t)blockIdx.x * N;
+    double *stt = a.sc_tot + (size_t)blockIdx.x * N;
+    if (threadIdx.x == 0) a.sc_n[blockIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < N; k += BLOCK) {
+        const size_t ix = (size_t)k * a.W + r;
+        const double t = fm[ix] + fi[ix] + fd[ix];
+        if (t > 0.0 && t > thr) {
+            const int s = atomicAdd(&a.sc_n[blockIdx.x], 1);
+            sn[s] = (uint32_t)k;
+            stt[s] = t;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int n = a.sc_n[blockIdx.x];
+    const int K = PHMM_MAX_ACTIVE_NODES;
+    // largest T with count(v >= T) >= K   (bit patterns of positive doubles are ordered)
+    unsigned long long lo = 0ull, hi = (unsigned long long)__double_as_longlong(tmax);
+    while (lo < hi) {
+        const unsigned long long mid = lo + (hi - lo + 1ull) / 2ull;
+        int c = 0;
+        for (int j = threadIdx.x; j < n; j += BLOCK) c += (unsigned long long)__double_as_longlong(stt[j]) >= mid;
+        c = block_count(c, &cnt);
+        if (c >= K) lo = mid;
+        else hi = mid - 1ull;
+    }
+    const unsigned long long T = lo;
+    int above = 0;
+    for (int j = threadIdx.x; j < n; j += BLOCK) above += (unsigned long long)__double_as_longlong(stt[j]) > T;
+    above = block_count(above, &cnt);
+    const int need_ties = K - above;
+    // smallest node id bound B with count(v == T && node <= B) >= need_ties
+    uint32_t blo = 0u, bhi = (uint32_t)N - 1u;
+    while (blo < bhi) {
+        const uint32_t mid = blo + (bhi - blo) / 2u;
+        int c = 0;
+        for (int j = threadIdx.x; j < n; j += BLOCK)
+            c += ((unsigned long long)__double_as_longlong(stt[j]) == T && sn[j] <= mid) ? 1 : 0;
+        c = block_count(c, &cnt);
+        if (c >= need_ties) bhi = mid;
+        else blo = mid + 1u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += BLOCK) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(stt[j]);
+        if (b > T || (b == T && sn[j] <= blo)) {
+            const int s = atomicAdd(&cnt, 1);
+            if (s < K) {
+                a.cand_node[(size_t)gi * K + s] = sn[j];
+                a.cand_tot[(size_t)gi * K + s] = stt[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.cand_n[gi] = cnt < K ? cnt : K;
+}
+
+struct SparseFwdArgs {
+    SparseModel M;
+    DenseArgs d;  // dense warm-up tables of the chunk
+    int W;
+    const int *sw;
+    const uint32_t *cand_node;
+    const double *cand_tot;
+    const int *cand_n;
+    const uint32_t *lanes;  // [n] flattened (g*W + r) of the reads handled by this launch
+    const uint8_t *bases;   // chunk-transposed full-length bases [ng][Lb][W]
+    int Lb;
+    double ratio_lin;
+    double *out_logp;  // [ng*W]
+    uint32_t *err;     // [ng*W]
+    // optional table storage (generate_mappings): one record per sparse position
+    RecPool pool;
+    const uint64_t *lane_pos0;  // [ng*W] first position index of each lane
+};
+
+template <int CAP>
+__global__ void __launch_bounds__(64) sparse_forward_kernel(const SparseFwdArgs a) {
+    __shared__ FVec<CAP> cols[2];
+    __shared__ FScratch<CAP> sc;
+    const int lane = threadIdx.x;
+    const uint32_t gi = a.lanes[blockIdx.x];
+    const int g = (int)(gi / a.W), r = (int)(gi % a.W);
+    const int len = a.d.len[gi];
+    const int s0 = a.sw[gi];
+    const size_t NW = (size_t)a.d.N * a.W;
+    if (lane == 0) sc.dropped = 0;
+    // ---- first sparse column: top list = candidates of dense column s0-1 sorted by
+    // (total desc, node asc) = the reference's stable sort over the dense nodevec
+    const int nc = a.cand_n[gi];
+    uint32_t err = 0;
+    if (nc > CAP) err |= SP_ERR_CAPACITY;
+    FVec<CAP> &c0 = cols[s0 & 1];
+    fv_clear(c0);
+    __syncthreads();
+    if (!err) {
+        const uint32_t *cn = a.cand_node + (size_t)gi * PHMM_MAX_ACTIVE_NODES;
+        const double *ct = a.cand_tot + (size_t)gi * PHMM_MAX_ACTIVE_NODES;
+        for (int j = lane; j < nc; j += 64) {
+            const double v = ct[j];
+            const uint32_t id = cn[j];
+            int rank = 0;
+            for (int q = 0; q < nc; q++) {
+                const double u = ct[q];
+                rank += (u > v) || (u == v && cn[q] < id);
+            }
+            c0.id[rank] = id;
+            c0.m[rank] = c0.i[rank] = c0.d[rank] = 0.0;
+        }
+        __syncthreads();
+        for (int j = lane; j < nc; j += 64) {
+            const uint32_t cell = fv_cell(c0, c0.id[j]);
+            c0.hslot[cell] = (uint16_t)j;
+        }
+        if (lane == 0) c0.n = nc;
+        __syncthreads();
+        PrevRef<CAP> pr{};
+        pr.vec = nullptr;
+        pr.gm = a.d.Fm + ((size_t)g * a.d.Lc + (s0 - 1)) * NW;
+        pr.gi = a.d.Fi + ((size_t)g * a.d.Lc + (s0 - 1)) * NW;
+        pr.gd = a.d.Fd + ((size_t)g * a.d.Lc + (s0 - 1)) * NW;
+        pr.W = a.W;
+        pr.lane = r;
+        pr.sc = 1.0;
+        pr.E = a.d.FE[((size_t)g * (a.d.Lc + 1) + (s0 - 1)) * a.W + r];
+        pr.is_init = false;
+        fwd_adaptive_step<CAP>(a.M, pr, c0, sc, a.bases[((size_t)g * a.Lb + s0) * a.W + r], s0);
+        if (a.pool.base && !store_record<CAP>(a.pool, a.lane_pos0[gi] + s0, c0)) err |= SP_ERR_POOL;
+        for (int pos = s0 + 1; pos < len; pos++) {
+            FVec<CAP> &prev = cols[(pos + 1) & 1];
+            FVec<CAP> &cur = cols[pos & 1];
+            select_top<CAP>(prev, cur, sc, true, a.ratio_lin, 0);
+            PrevRef<CAP> p2{};
+            p2.vec = &prev;
+            p2.E = prev.E;
+            p2.is_init = false;
+            fwd_adaptive_step<CAP>(a.M, p2, cur, sc, a.bases[((size_t)g * a.Lb + pos) * a.W + r], pos);
+            if (a.pool.base && !store_record<CAP>(a.pool, a.lane_pos0[gi] + pos, cur)) err |= SP_ERR_POOL;
+        }
+    }
+    const double lp = err ? NAN : fv_log_end(a.M, cols[(len - 1) & 1]);
+    if (lane == 0) {
+        a.out_logp[gi] = lp;
+        a.err[gi] = err | (sc.dropped && CAP < PHMM_MAX_ACTIVE_NODES ? SP_ERR_CAPACITY : 0u);
+    }
+}
+
+namespace {
+
+template <int W> void launch_col_count(const WarmArgs &wa, int col) {
+    hipLaunchKernelGGL(col_count<W>, dim3(wa.d.nblk, wa.d.ng), dim3(BLOCK), 0, current_stream(), wa, col);
+}
+void launch_col_count_w(int W, const WarmArgs &wa, int col) {
+    switch (W) {
+    case 1: launch_col_count<1>(wa, col); break;
+    case 2: launch_col_count<2>(wa, col); break;
+    case 4: launch_col_count<4>(wa, col); break;
+    case 8: launch_col_count<8>(wa, col); break;
+    case 16: launch_col_count<16>(wa, col); break;
+    case 32: launch_col_count<32>(wa, col); break;
+    case 64: launch_col_count<64>(wa, col); break;
+    default: PHMM_THROW(PHMM_EINTERNAL, "bad read-group width");
+    }
+}
+
+}  // namespace
+
+// PHMMModel::to_full_prob_reads without mappings: forward_sparse_score_only(use_max_ratio = true)
+void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total,
+                            MappingSink *sink) {
+    hipStream_t s = current_stream();
+    CallStats &st = stats();
+    st = CallStats();
+    const uint64_t R = reads->R;
+    if (m->dev.max_degree > 8)
+        PHMM_THROW(PHMM_EINVAL, "sparse path supports node degree <= 8 (MultiDbg MAX_DEGREE is 5)");
+    ensure_logib(m, reads->max_len + 1);
+    const phmm_params &prm = m->params;
+    Plan plan = make_plan(m, reads, 0);
+    const int W = plan.W;
+    const size_t NW = (size_t)m->N * W;
+    const uint64_t limit = workspace_limit();
+    std::vector<double> lf(R, 0.0);
+
+    DenseArgs base{};
+    fill_model_args(base, m);
+    base.nblk = plan.nblk;
+    base.nblk8 = plan.nblk8;
+    base.npt = plan.npt;
+    base.eall = 0;
+    base.want_freq = 0;
+
+    DevBuf warm;  // per-chunk warm-up control arrays
+    DevBuf fpool, fpool_meta;  // forward table records (generate_mappings)
+    int g0 = 0;
+    while (g0 < plan.ng_total) {
+        const uint32_t r0 = plan.order[(size_t)g0 * W];
+        const int Lfull = (int)(reads->off[r0 + 1] - reads->off[r0]);
+        // dense columns kept: at most n_warmup (+1 so that the launch that writes d of the last
+        // dense column has somewhere to put its speculative next column)
+        const int Lc = (int)std::min<int64_t>(Lfull, prm.n_warmup + 2);
+        const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8;
+        int ngc = (int)std::min<uint64_t>(plan.ng_total - g0, std::max<uint64_t>(1, limit / std::max<size_t>(per_group, 1)));
+        DenseArgs a = base;
+        a.ng = ngc;
+        a.Lc = Lc;
+        size_t tb = 0, mb = 0;
+        layout(a, W, false, nullptr, nullptr, tb, mb);
+        m->ws_tables.reserve(tb);
+        m->ws_misc.reserve(mb);
+        layout(a, W, false, m->ws_tables.p, m->ws_misc.p, tb, mb);
+        HIP_CHECK(hipMemsetAsync(m->ws_misc.p, 0, mb, s));
+        const int lanes = ngc * W;
+        // warm-up control
+        size_t wb = 0;
+        auto carve = [&](size_t bytes) {
+            wb = (wb + 255) / 256 * 256;
+            size_t o = wb;
+            wb += bytes;
+            return o;
+        };
+        const size_t o_sw = carve(sizeof(int) * lanes), o_cnt = carve(sizeof(int) * lanes),
+                     o_cn = carve(sizeof(int) * lanes), o_und = carve(sizeof(int)),
+                     o_cnode = carve(sizeof(uint32_t) * (size_t)lanes * PHMM_MAX_ACTIVE_NODES),
+                     o_ctot = carve(sizeof(double) * (size_t)lanes * PHMM_MAX_ACTIVE_NODES),
+                     o_lanes = carve(sizeof(uint32_t) * lanes), o_out = carve(sizeof(double) * lanes),
+                     o_err = carve(sizeof(uint32_t) * lanes),
+                     o_bases = carve((size_t)ngc * Lfull * W);
+        warm.reserve(wb);
+        char *wp = (char *)warm.p;
+        HIP_CHECK(hipMemsetAsync(wp, 0, o_cnode, s));
+        HIP_CHECK(hipMemsetAsync(wp + o_sw, 0xff, sizeof(int) * lanes, s));  // sw = -1
+
+        // host staging (the full-length transposed bases are needed by the sparse kernel)
+        std::vector<uint8_t> hb((size_t)ngc * Lc * W, 0xff), hbf((size_t)ngc * Lfull * W, 0xff);
+        std::vector<int> hl((size_t)lanes, 0);
+        uint64_t dense_cells = 0;
+        for (int g = 0; g < ngc; g++)
+            for (int r = 0; r < W; r++) {
+                const size_t slot = (size_t)(g0 + g) * W + r;
+                if (slot >= R) continue;
+                const uint32_t rd = plan.order[slot];
+                const uint64_t len = reads->off[rd + 1] - reads->off[rd];
+                hl[(size_t)g * W + r] = (int)len;
+                for (uint64_t i = 0; i < len; i++) {
+                    const uint8_t b = reads->bases[reads->off[rd] + i];
+                    if ((int)i < Lc) hb[((size_t)g * Lc + i) * W + r] = b;
+                    hbf[((size_t)g * Lfull + i) * W + r] = b;
+                }
+            }
+        std::vector<double> hib;
+        host_logib(m, (size_t)Lc, hib);
+        // the dense kernels see lengths clamped to the kept columns; the true lengths are
+        // restored for the sparse kernel below
+        std::vector<int> hlc(hl);
+        for (auto &v : hlc) v = std::min(v, Lc);
+        HIP_CHECK(hipMemcpyAsync((void *)a.bases, hb.data(), hb.size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync((void *)a.len, hlc.data(), hlc.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync((void *)a.logib, hib.data(), hib.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(wp + o_bases, hbf.data(), hbf.size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+
+        WarmArgs wa{};
+        wa.d = a;
+        wa.sw = (int *)(wp + o_sw);
+        wa.cnt = (int *)(wp + o_cnt);
+        wa.cand_n = (int *)(wp + o_cn);
+        wa.undecided = (int *)(wp + o_und);
+        wa.cand_node = (uint32_t *)(wp + o_cnode);
+        wa.cand_tot = (double *)(wp + o_ctot);
+        wa.ratio_lin = std::exp(-prm.active_node_max_ratio);
+        wa.n_warmup = (int)prm.n_warmup;
+        wa.threshold = (int)prm.warmup_threshold;
+
+        // ---- dense warm-up with per-read switch decisions
+        int pos = 0;
+        for (;; pos++) {
+            launch_fwd_step(W, a, pos);  // column pos (if pos < Lc), d + totals maximum of column pos-1
+            st.launches[0]++;
+            if (pos >= 1) launch_col_count_w(W, wa, pos - 1);
+            HIP_CHECK(hipMemsetAsync(wa.undecided, 0, sizeof(int), s));
+            hipLaunchKernelGGL(warm_decide, dim3((lanes + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, wa, pos, lanes);
+            int und = 0;
+            HIP_CHECK(hipMemcpyAsync(&und, wa.undecided, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (und == 0) break;
+            if (pos >= Lc) PHMM_THROW(PHMM_EINTERNAL, "warm-up did not terminate");
+        }
+        // reads that ended inside the warm-up: fe of their last (dense) column
+        launch_fwd_finish(W, a);
+        std::vector<int> hsw(lanes);
+        std::vector<int> hcn(lanes);
+        std::vector<double> tlf(lanes);
+        HIP_CHECK(hipMemcpyAsync(hsw.data(), wa.sw, sizeof(int) * lanes, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(hcn.data(), wa.cand_n, sizeof(int) * lanes, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(tlf.data(), a.logPf, sizeof(double) * lanes, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<uint32_t> sparse_lanes, need400;
+        for (int gi = 0; gi < lanes; gi++) {
+            if (hl[gi] == 0) continue;
+            dense_cells += (uint64_t)std::min(hsw[gi] + 1, hl[gi]) * m->N;
+            if (hsw[gi] < hl[gi]) {
+                if (hcn[gi] > PHMM_MAX_ACTIVE_NODES) need400.push_back((uint32_t)gi);
+                sparse_lanes.push_back((uint32_t)gi);
+            }
+        }
+        st.cells[0] += dense_cells;
+        DevBuf sel;
+        if (!need400.empty()) {
+            // forced switch at n_warmup with > 400 nodes inside the ratio: keep the 400 best
+            const size_t nn = need400.size();
+            size_t sb = 0;
+            auto c2 = [&](size_t bytes) {
+                sb = (sb + 255) / 256 * 256;
+                size_t o = sb;
+                sb += bytes;
+                return o;
+            };
+            const size_t p_need = c2(sizeof(uint32_t) * nn), p_n = c2(sizeof(int) * nn),
+                         p_node = c2(sizeof(uint32_t) * nn * m->N), p_tot = c2(sizeof(double) * nn * m->N);
+            sel.reserve(sb);
+            char *sp = (char *)sel.p;
+            HIP_CHECK(hipMemcpyAsync(sp + p_need, need400.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice, s));
+            Top400Args ta{};
+            ta.d = a;
+            ta.W = W;
+            ta.sw = wa.sw;
+            ta.need = (const uint32_t *)(sp + p_need);
+            ta.sc_node = (uint32_t *)(sp + p_node);
+            ta.sc_tot = (double *)(sp + p_tot);
+            ta.sc_n = (int *)(sp + p_n);
+            ta.cand_node = wa.cand_node;
+            ta.cand_tot = wa.cand_tot;
+            ta.cand_n = wa.cand_n;
+            ta.ratio_lin = wa.ratio_lin;
+            hipLaunchKernelGGL(select_top400, dim3((unsigned)nn), dim3(BLOCK), 0, s, ta);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+
+        // ---- sparse continuation, one wave per read
+        std::vector<double> slp(lanes, 0.0);
+        if (!sparse_lanes.empty()) {
+            // the sparse kernel indexes lengths and bases of the full reads
+            HIP_CHECK(hipMemcpyAsync((void *)a.len, hl.data(), hl.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(wp + o_lanes, sparse_lanes.data(), sparse_lanes.size() * sizeof(uint32_t),
+                                     hipMemcpyHostToDevice, s));
+            SparseFwdArgs fa{};
+            fa.M = sparse_model_of(m);
+            fa.d = a;
+            fa.d.Lc = Lc;
+            fa.W = W;
+            fa.sw = wa.sw;
+            fa.cand_node = wa.cand_node;
+            fa.cand_tot = wa.cand_tot;
+            fa.cand_n = wa.cand_n;
+            fa.lanes = (const uint32_t *)(wp + o_lanes);
+            fa.bases = (const uint8_t *)(wp + o_bases);
+            fa.Lb = Lfull;
+            fa.ratio_lin = wa.ratio_lin;
+            fa.out_logp = (double *)(wp + o_out);
+            fa.err = (uint32_t *)(wp + o_err);
+            // table storage for generate_mappings: one record per sparse position
+            std::vector<uint64_t> lane_pos0(lanes + 1, 0);
+            for (int gi = 0; gi < lanes; gi++) lane_pos0[gi + 1] = lane_pos0[gi] + (uint64_t)hl[gi];
+            const uint64_t n_pos = lane_pos0[lanes];
+            uint64_t pool_cap = 0;
+            if (sink) {
+                uint64_t sparse_pos = 0;
+                for (uint32_t gi : sparse_lanes) sparse_pos += (uint64_t)(hl[gi] - hsw[gi]);
+                pool_cap = sparse_pos * 1024 + (uint64_t)sparse_lanes.size() * 65536 + (1u << 20);
+            }
+            for (int attempt = 0;; attempt++) {
+                if (sink) {
+                    fpool.reserve(pool_cap);
+                    fpool_meta.reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1) * 2);
+                    HIP_CHECK(hipMemsetAsync(fpool_meta.p, 0, fpool_meta.bytes, s));
+                    fa.pool.base = fpool.as<uint8_t>();
+                    fa.pool.cap = pool_cap;
+                    fa.pool.top = fpool_meta.as<unsigned long long>();
+                    fa.pool.off = (uint64_t *)(fpool_meta.as<char>() + 8);
+                    uint64_t *d_lp0 = fa.pool.off + n_pos;
+                    HIP_CHECK(hipMemcpyAsync(d_lp0, lane_pos0.data(), sizeof(uint64_t) * lanes, hipMemcpyHostToDevice, s));
+                    fa.lane_pos0 = d_lp0;
+                }
+                hipLaunchKernelGGL((sparse_forward_kernel<PHMM_MAX_ACTIVE_NODES>), dim3((unsigned)sparse_lanes.size()),
+                                   dim3(64), 0, s, fa);
+                HIP_CHECK(hipGetLastError());
+                st.launches[2]++;
+                std::vector<uint32_t> herr(lanes);
+                HIP_CHECK(hipMemcpyAsync(slp.data(), fa.out_logp, sizeof(double) * lanes, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipMemcpyAsync(herr.data(), fa.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                bool pool_full = false;
+                for (uint32_t gi : sparse_lanes) {
+                    if (herr[gi] & SP_ERR_POOL) pool_full = true;
+                    else if (herr[gi])
+                        PHMM_THROW(PHMM_ECAPACITY, "sparse forward: frontier error " + std::to_string(herr[gi]));
+                }
+                if (!pool_full) break;
+                if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "forward table pool keeps overflowing");
+                pool_cap *= 2;
+            }
+            if (sink) {
+                MapChunk mc{};
+                mc.m = m;
+                mc.W = W;
+                mc.Lc = Lc;
+                mc.Lfull = Lfull;
+                mc.ngc = ngc;
+                mc.lanes = lanes;
+                mc.a = a;
+                mc.fa_M = fa.M;
+                mc.d_sw = wa.sw;
+                mc.d_bases_full = fa.bases;
+                mc.fpool = fa.pool;
+                mc.d_lane_pos0 = fa.lane_pos0;
+                mc.hl = &hl;
+                mc.hsw = &hsw;
+                mc.lane_pos0 = &lane_pos0;
+                mc.ratio_lin = wa.ratio_lin;
+                mc.d_logp_sparse = fa.out_logp;
+                mc.cand_node = wa.cand_node;
+                mc.cand_tot = wa.cand_tot;
+                mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
+            }
+        } else if (sink) {
+            // every read of the chunk ended inside the dense warm-up
+            std::vector<uint64_t> lane_pos0(lanes + 1, 0);
+            for (int gi = 0; gi < lanes; gi++) lane_pos0[gi + 1] = lane_pos0[gi] + (uint64_t)hl[gi];
+            HIP_CHECK(hipMemcpyAsync((void *)a.len, hl.data(), hl.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            MapChunk mc{};
+            mc.m = m;
+            mc.W = W;
+            mc.Lc = Lc;
+            mc.Lfull = Lfull;
+            mc.ngc = ngc;
+            mc.lanes = lanes;
+            mc.a = a;
+            mc.fa_M = sparse_model_of(m);
+            mc.d_sw = wa.sw;
+            mc.d_bases_full = (const uint8_t *)(wp + o_bases);
+            mc.hl = &hl;
+            mc.hsw = &hsw;
+            mc.lane_pos0 = &lane_pos0;
+            mc.ratio_lin = wa.ratio_lin;
+            mc.d_logp_sparse = (double *)(wp + o_out);
+            mc.cand_node = wa.cand_node;
+            mc.cand_tot = wa.cand_tot;
+            mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
+        }
+        for (int gi = 0; gi < lanes; gi++) {
+            const size_t slot = (size_t)g0 * W + gi;
+            if (slot >= R || hl[gi] == 0) continue;
+            const uint32_t rd = plan.order[slot];
+            lf[rd] = hsw[gi] < hl[gi] ? slp[gi] : tlf[gi];
+        }
+        g0 += ngc;
+    }
+    double tot = 0.0;
+    for (uint64_t r = 0; r < R; r++) tot += lf[r];
+    put_doubles(out_logp, lf.data(), R);
+    put_doubles(out_total, &tot, 1);
+}
+
+}  // namespace phmm

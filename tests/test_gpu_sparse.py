@@ -109,3 +109,87 @@ def test_mapping_errors(gpu_lib, oracle):
     other = D.ReadCollection(reads[:1])
     with pytest.raises(D.PhmmError):
         gm.to_full_prob_reads(other, D.Mappings.from_arrays(rc, *mp))
+
+
+@pytest.mark.parametrize("cfg", [(300, 12, 0.001, 9), (600, 16, 0.001, 3), (600, 12, 0.01, 3), (900, 16, 0.003, 21)])
+def test_adaptive_sparse_forward_matches_oracle(gpu_lib, oracle, cfg):
+    """to_full_prob_reads without mappings = forward_sparse_score_only(use_max_ratio=true)
+    (forward.rs:158-206): dense warm-up, per-read switch, adaptive frontier."""
+    gl, k, p, seed = cfg
+    arrays, sg = small_dbg_model(gl, k, p, seed=seed)
+    reads = D.sample_reads(arrays, 10 ** 9, 150, seed=seed + 1, max_reads=40)
+    reads = [r[: max(3, len(r) - (j * 11) % 140)] for j, r in enumerate(reads)]  # some end inside the warm-up
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    tot, lp = gm.to_full_prob_reads(rc, None, True)
+    olp = om.full_prob_reads(reads, None, True, n_threads=8)
+    assert np.max(np.abs(lp - olp)) < 1e-6, np.abs(lp - olp).max()  # BASELINE.json: |d lnP| < 1e-6 per read
+    lf, _, _ = gm.run_dense(rc, False, False)
+    assert abs(lf.sum() - tot) < 1e-4 * len(reads)  # hmmv2/tests/dbg.rs:44-45
+
+
+def test_adaptive_sparse_top_k_mode_is_rejected(gpu_lib, oracle):
+    arrays, sg, reads, om, mp = _setup(oracle, n_reads=2)
+    with pytest.raises(D.PhmmError):
+        D.PHMMModel(arrays).to_full_prob_reads(D.ReadCollection(reads), None, False)
+
+
+def _compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6):
+    gpo, gnd, glp = gpu_arrays
+    opo, ond, olp = orc_arrays
+    assert gpo.shape == opo.shape
+    g = 0
+    for r in reads:
+        for i in range(len(r)):
+            a0, a1 = int(gpo[g]), int(gpo[g + 1])
+            b0, b1 = int(opo[g]), int(opo[g + 1])
+            gn, gl = gnd[a0:a1], glp[a0:a1]
+            on, ol = ond[b0:b1], olp[b0:b1]
+            # entries that matter (prob > e^min_logp) must agree in order, node and value
+            ka, kb = int((gl > min_logp).sum()), int((ol > min_logp).sum())
+            assert ka == kb, (i, gn, gl, on, ol)
+            # (nodes with equal probability -- e.g. the two haplotype copies of a k-mer -- may swap)
+            assert np.max(np.abs(gl[:ka] - ol[:kb]), initial=0.0) < tol, (i, gl, ol)
+            assert sorted(gn[:ka].tolist()) == sorted(on[:kb].tolist()), (i, gn, on)
+            od = dict(zip(on[:kb].tolist(), ol[:kb].tolist()))
+            assert all(abs(od[n] - l) < tol for n, l in zip(gn[:ka].tolist(), gl[:ka].tolist())), (i, gn, gl, on, ol)
+            # lists are sorted descending and respect the ratio
+            assert np.all(np.diff(gl) <= 1e-12)
+            if a1 > a0:
+                assert gl[0] - gl[-1] < 30.0 + 1e-9
+            g += 1
+
+
+def test_generate_mappings_toy_kat(gpu_lib):
+    """multi_dbg/posterior/test.rs:544-576 (hint_for_toy): best node per base on toy::repeat()."""
+    import json, os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_hmmv2.json")))["toy_repeat_hints"]
+    sg, k = D.toy_repeat()
+    gm = D.PHMMModel(sg.to_non_zero_phmm(D.PHMMParams.uniform(kat["p"]).with_(n_warmup=k)))
+    for read, best in kat["reads"].items():
+        rc = D.ReadCollection([read.encode()])
+        mp, nf = gm.generate_mappings(rc, None, True)
+        assert [mp.nodes(0, i)[0] for i in range(len(read))] == best
+
+
+@pytest.mark.parametrize("cfg", [(300, 12, 0.001, 9, 30), (600, 16, 0.001, 3, 40), (600, 12, 0.01, 3, 24), (900, 16, 0.003, 21, 70)])
+def test_generate_mappings_matches_oracle(gpu_lib, oracle, cfg):
+    """generate_mappings(reads, None, true) = run_sparse_adaptive + to_mapping_by_score_ratio
+    (hint.rs:193-220; freq.rs:60-68; backward.rs:101-142)."""
+    gl, k, p, seed, n_reads = cfg
+    arrays, sg = small_dbg_model(gl, k, p, seed=seed, min_copy_num=1)
+    reads = D.sample_reads(arrays, 10 ** 9, 150, seed=seed + 1, max_reads=n_reads)
+    reads = [r[: max(1, len(r) - (j * 13) % 149)] for j, r in enumerate(reads)]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    mp, nf = gm.generate_mappings(rc, None, True)
+    omp, onf = om.generate_mappings(reads, None, True, n_threads=8)
+    _compare_mappings(reads, mp.arrays(), omp)
+    assert np.max(np.abs(nf - onf)) < 1e-6
+    assert np.max(np.abs(mp.to_node_freqs(arrays.n_nodes) - nf)) < 1e-12
+    # the mappings drive the hinted likelihood (hmmv2/tests/dbg.rs:85-114): 1e-4 on the total
+    # (reads of a few bases are left out: their first lists hold 400 of the N nodes inside the ratio)
+    _, lp_hint = gm.to_full_prob_reads(rc, mp)
+    _, lp_sparse = gm.to_full_prob_reads(rc, None)
+    long_enough = np.array([len(r) >= 2 * k for r in reads])
+    assert np.max(np.abs(lp_hint - lp_sparse)[long_enough], initial=0.0) < 1e-4
