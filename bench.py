@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Headline benchmark: read-bases/s through forward+backward P(R|X) on MI355X.
 
-One "step" = one pass of the hot path over the whole synthetic read set resident on
-the GPU: per-read ln P(R|X) (forward), the backward pass and the per-node usage
-posteriors.  At N>1 every rank holds the same graph and its own 20x read shard
-(weak scaling); the only collective is one RCCL all-reduce of
-[sum ln P, node_freq[N]] per step.
+One "step" = one pass of the hot path over the whole synthetic read set of this rank:
 
-Prints ONE JSON line on rank 0 (contract in the task statement).
+  cfg3 (default, BASELINE.json configs[2] -- the configuration the target is quoted on):
+      100 kb diploid genome (1 % divergence), 20x HiFi reads (p = 0.001, L = 1000), k = 40 DBG.
+      step = PHMMModel::generate_mappings(reads, None, true) = run_sparse_adaptive:
+      forward_sparse (dense warm-up, then the <= 400-node frontier) + backward_by_forward +
+      per-position node posteriors (Mappings) + per-node usage sums, exactly what `infer`
+      runs once per k; per-read ln P(R|X) comes out of the same pass.
+  cfg2 (BASELINE.json configs[1]): 10 kb haploid, dense forward + backward + node posteriors.
+
+At N > 1 every rank holds the same graph and its own 20x read shard (weak scaling); the only
+collective is ONE RCCL all-reduce of [sum ln P, node_freq[N]] per step.
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -24,11 +30,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # BASELINE.json configs[1]
+    "cfg3": dict(genome=100_000, haplotypes=2, k=40, coverage=20, read_len=1000, p=0.001, mode="sparse",
+                 desc="cfg3: synthetic 100 kb diploid genome (1% divergence), 20x HiFi reads (p=0.001, L=1000), "
+                      "k=40 DBG; sparse-adaptive forward+backward+posteriors (generate_mappings)"),
     "cfg2": dict(genome=10_000, haplotypes=1, k=40, coverage=20, read_len=1000, p=0.001, mode="dense",
                  desc="cfg2: synthetic 10 kb haploid genome, 20x HiFi reads (p=0.001, L=1000), k=40 DBG, "
                       "dense forward+backward+node posteriors"),
-    # BASELINE.json configs[0] shape (plumbing)
     "cfg1": dict(genome=1_000, haplotypes=1, k=16, coverage=10, read_len=200, p=0.001, mode="dense",
                  desc="cfg1: 1 kb haploid, 10x, L=200, k=16, dense forward+backward"),
 }
@@ -37,38 +44,52 @@ WORKLOADS = {
 def build_workload(name: str, rank: int):
     import dbgphmm_amd as D
     w = WORKLOADS[name]
-    hap = D.random_genome(w["genome"], seed=2)
-    haps = [hap] if w["haplotypes"] == 1 else [hap, D.diverge(hap, 0.01, seed=3)]
+    hap = D.random_genome(w["genome"], seed=3)
+    haps = [hap] if w["haplotypes"] == 1 else [hap, D.diverge(hap, 0.01, seed=4)]
     sg = D.dbg_from_haplotypes(haps, w["k"])
     param = D.PHMMParams.uniform(w["p"]).with_(n_warmup=w["k"])
-    arrays = D.vectorised_to_phmm(sg, param, 0)
-    total = w["coverage"] * w["genome"] * w["haplotypes"]
+    # mapping generation uses the non-zero PHMM (multi_dbg/posterior.rs:616-619); with true copy
+    # numbers >= 1 everywhere it equals to_phmm
+    arrays = D.vectorised_to_phmm(sg, param, 1 if w["mode"] == "sparse" else 0)
+    total = w["coverage"] * sum(len(h) for h in haps)
     reads = D.sample_reads(arrays, total, w["read_len"], seed=1000 + rank)
     return arrays, reads, w
 
 
-def cpu_baseline(arrays, reads, budget_s: float = 20.0):
-    """The oracle (C restatement of the reference, OpenMP over reads = the rayon stand-in)
-    timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(arrays, reads, mode: str, budget_s: float = 20.0):
+    """The oracle (C restatement of the reference; OpenMP over reads = the rayon stand-in) timed on
+    this box's host cores on a bounded sample of the same workload."""
     from oracle import oracle as O
     O.build()
     om = O.Model(arrays)
     cores = min(os.cpu_count() or 1, 16)
-    sample = list(reads[:cores])
-    # one short calibration read, then as many full reads as fit the budget
+
+    def run(sample, threads):
+        if mode == "dense":
+            om.run_dense_reads(sample, n_threads=threads)
+        else:
+            om.generate_mappings(sample, None, True, n_threads=threads)
+
+    probe = reads[0][: (60 if mode == "dense" else 120)]
     t0 = time.time()
-    om.run_dense_reads([sample[0][:50]], n_threads=1)
-    per_base = (time.time() - t0) / 50.0
-    bases_budget = max(1, int(budget_s / max(per_base, 1e-9)))
-    per_read = max(20, min(len(sample[0]), bases_budget))
-    sample = [r[:per_read] for r in sample]
+    run([probe], 1)
+    t_probe = time.time() - t0
+    full = [r for r in reads if len(r) >= 0.9 * max(map(len, reads))][:cores] or list(reads[:cores])
+    if mode == "dense":
+        per_read = max(20, min(len(full[0]), int(budget_s / max(t_probe / len(probe), 1e-9))))
+        sample = [r[:per_read] for r in full]
+    else:
+        # cost is dominated by the ~14 dense warm-up columns of every read: keep whole reads
+        n = max(1, min(len(full), int(cores * budget_s / max(t_probe * 1.5, 1e-3))))
+        sample = full[:n]
     t0 = time.time()
-    om.run_dense_reads(sample, n_threads=cores)
+    run(sample, cores)
     dt = time.time() - t0
     nb = sum(len(r) for r in sample)
+    what = "dense forward+backward+node posteriors" if mode == "dense" else \
+        "generate_mappings (sparse-adaptive forward + backward_by_forward + posteriors)"
     return {"value": nb / dt, "unit": "bases/s", "cores": cores, "kind": "port",
-            "sample": f"{len(sample)} reads x {per_read} bases of the same workload, dense forward+backward+"
-                      f"node posteriors, {cores} OpenMP threads, {dt:.1f} s"}
+            "sample": f"{len(sample)} reads, {nb} bases of the same workload, {what}, {cores} OpenMP threads, {dt:.1f} s"}
 
 
 def main():
@@ -76,7 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -85,18 +106,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import dbgphmm_amd as D
     from dbgphmm_amd import _ffi
+    from dbgphmm_amd import dist as PD
     L = _ffi.lib()
     _ffi.check(L.phmm_set_device(local_rank))
     _ffi.check(L.phmm_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
@@ -108,34 +128,41 @@ def main():
     n_bases = rc.total_bases()
     N = model.n_nodes
     out_logp = torch.empty(len(rc), dtype=torch.float64, device=dev)
-    # [sum ln P, node_freq[N]] : the one buffer that is all-reduced
+    # [sum ln P, node_freq[N]]: the one buffer that is all-reduced
     red = torch.zeros(1 + N, dtype=torch.float64, device=dev)
+    state = {}
 
     def step():
-        model.run_dense(rc, True, True, out_logp=out_logp, out_node_freq=red[1:])
-        red[0] = out_logp.sum()
+        if w["mode"] == "dense":
+            model.run_dense(rc, True, True, out_logp=out_logp, out_node_freq=red[1:])
+            red[0] = out_logp.sum()
+        else:
+            mp, _ = model.generate_mappings(rc, None, True, out_node_freq=red[1:])
+            state["mappings"] = mp
+            tot, _ = mp.read_logp(out_logp)  # per-read ln P(R|X) of the same forward pass
+            red[0] = tot
         if dist is not None:
-            dist.all_reduce(red)
+            PD.all_reduce_partial(red, dist)
+
+    def stats(which):
+        ms, n, c = C.c_double(), C.c_uint64(), C.c_uint64()
+        L.phmm_last_call_stats(which, C.byref(ms), C.byref(n), C.byref(c))
+        return ms.value, n.value, c.value
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    fwd_ms = bwd_ms = 0.0
-    fwd_n = bwd_n = 0
-    cells = 0
+    acc = {0: [0.0, 0, 0], 1: [0.0, 0, 0]}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        ms, n, c = C.c_double(), C.c_uint64(), C.c_uint64()
-        L.phmm_last_call_stats(0, C.byref(ms), C.byref(n), C.byref(c))
-        fwd_ms += ms.value
-        fwd_n += n.value
-        cells = c.value
-        L.phmm_last_call_stats(1, C.byref(ms), C.byref(n), C.byref(c))
-        bwd_ms += ms.value
-        bwd_n += n.value
+        for k in (0, 1):
+            ms, n, c = stats(k)
+            acc[k][0] += ms
+            acc[k][1] += n
+            acc[k][2] += c
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -150,15 +177,36 @@ def main():
     else:
         total_bases = float(n_bases)
 
+    extra = {}
+    if w["mode"] == "sparse" and rank == 0:
+        # the inner loop of `infer` on the mappings just produced: hinted forward score
+        # (to_full_prob_reads with mappings, freq.rs:175-192), not part of the timed step
+        mp = state["mappings"]
+        model.to_full_prob_reads(rc, mp)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            tot, _lp = model.to_full_prob_reads(rc, mp)
+        torch.cuda.synchronize()
+        dth = (time.perf_counter() - t1) / reps
+        extra = {"hinted_forward_bases_per_s": n_bases / dth, "hinted_forward_ms": dth * 1e3,
+                 "sum_lnP_hinted": tot, "mean_mapping_list": mp.arrays()[1].shape[0] / max(n_bases, 1)}
+
     if rank == 0:
-        # roofline of the dominant kernel: bwd_step (backward column + fused posterior).
-        # Algorithmic bytes per cell: B write 24 + B prev read 24 + F re-read 24 = 72
-        # (forward step: F prev read 24 + F write 24 = 48); cells per launch = N x active reads.
-        cells_per_launch = cells / max(bwd_n // max(args.steps, 1), 1)
-        avg_s = (bwd_ms / max(bwd_n, 1)) * 1e-3
-        achieved = 72.0 * cells_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-        fwd_avg_s = (fwd_ms / max(fwd_n, 1)) * 1e-3
-        fwd_cells_per_launch = cells / max(fwd_n // max(args.steps, 1), 1)
+        def roof(k, bytes_per_cell):
+            ms, n, cells = acc[k]
+            if n == 0 or ms <= 0:
+                return None
+            avg_s = ms / n * 1e-3
+            cells_per_launch = cells / n
+            ach = bytes_per_cell * cells_per_launch / avg_s / 1e9
+            return {"avg_launch_us": avg_s * 1e6, "launches_per_step": n // max(args.steps, 1),
+                    "cells_per_launch": cells_per_launch, "algorithmic_bytes_per_cell": bytes_per_cell,
+                    "achieved": ach}
+        # dominant kernel: bwd_step (backward column + fused F(.)B posterior): B write 24 + B prev read 24 +
+        # F re-read 24 = 72 algorithmic bytes per cell; fwd_step: 24 + 24 = 48.
+        rb, rf = roof(1, 72.0), roof(0, 48.0)
         out = {
             "metric": "read-bases/sec through forward+backward P(R|X)",
             "value": total_bases * args.steps / dt,
@@ -173,18 +221,16 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": w["desc"], "n_nodes": N, "n_edges": model.n_edges, "reads_per_gpu": len(rc),
-                       "bases_per_gpu": n_bases, "cells_per_step_per_gpu": int(cells),
-                       "parallelism": f"reads sharded over {world} GPU(s); one all-reduce of [sum lnP, node_freq]"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "bwd_step", "avg_launch_us": avg_s * 1e6, "launches_per_step": bwd_n // max(args.steps, 1),
-                         "algorithmic_bytes_per_cell": 72,
-                         "fwd_step": {"avg_launch_us": fwd_avg_s * 1e6,
-                                      "achieved": 48.0 * fwd_cells_per_launch / fwd_avg_s / 1e9 if fwd_avg_s > 0 else 0.0,
-                                      "algorithmic_bytes_per_cell": 48}},
+                       "bases_per_gpu": n_bases, "dense_cells_per_step_per_gpu": int(acc[1][2] // max(args.steps, 1)),
+                       "parallelism": f"reads sharded over {world} GPU(s); one all-reduce of [sum lnP, node_freq[N]]",
+                       **extra},
+            "roofline": {"bound": "hbm", "achieved": rb["achieved"] if rb else 0.0, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (rb["achieved"] / 8000.0) if rb else 0.0, "traffic": None, "kernel": "bwd_step",
+                         **({k: v for k, v in rb.items() if k != "achieved"} if rb else {}),
+                         "fwd_step": rf},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(arrays, reads)
+            out["cpu_baseline"] = cpu_baseline(arrays, reads, w["mode"])
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -67,6 +67,7 @@ def lib():
         "phmm_mappings_total_entries": (u64, [vp]),
         "phmm_mappings_export": (i32, [vp, vp, vp, vp]),
         "phmm_mappings_node_freqs": (i32, [vp, u32, vp]),
+        "phmm_mappings_read_logp": (i32, [vp, vp, vp]),
         "phmm_mappings_destroy": (None, [vp]),
         "phmm_full_prob_reads": (i32, [vp, vp, vp, i32, vp, vp]),
         "phmm_full_prob_reads_candidates": (i32, [vp, vp, vp, u32, vp, vp, vp, vp]),
@@ -89,7 +90,7 @@ DECLARED_SYMBOLS = [
     "phmm_model_destroy", "phmm_reads_create", "phmm_reads_count", "phmm_reads_total_bases",
     "phmm_reads_destroy", "phmm_run_dense", "phmm_dense_tables", "phmm_mappings_create",
     "phmm_mappings_total_positions", "phmm_mappings_total_entries", "phmm_mappings_export",
-    "phmm_mappings_node_freqs", "phmm_mappings_destroy", "phmm_full_prob_reads",
+    "phmm_mappings_node_freqs", "phmm_mappings_read_logp", "phmm_mappings_destroy", "phmm_full_prob_reads",
     "phmm_full_prob_reads_candidates", "phmm_generate_mappings", "phmm_last_call_stats", "phmm_enable_timing",
 ]
 

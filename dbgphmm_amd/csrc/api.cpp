@@ -29,6 +29,13 @@ uint64_t workspace_limit() {
     return (uint64_t)(0.8 * (double)fr);
 }
 
+uint64_t table_budget(size_t owned) {
+    if (g_ws_limit) return g_ws_limit;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)16 << 30;
+    return (uint64_t)(0.8 * (double)(fr + owned));
+}
+
 void copy_out(void *dst, const void *src_dev, size_t bytes) {
     if (!dst || !bytes) return;
     hipPointerAttribute_t at;
@@ -310,6 +317,18 @@ int phmm_mappings_export(const phmm_mappings *mp, uint64_t *pos_off, uint32_t *n
     });
 }
 void phmm_mappings_destroy(phmm_mappings *mp) { delete mp; }
+
+int phmm_mappings_read_logp(const phmm_mappings *mp, double *out_logp, double *out_total) {
+    return guarded([&] {
+        if (!mp) PHMM_THROW(PHMM_EINVAL, "NULL mappings");
+        if (mp->read_logp.size() != mp->R)
+            PHMM_THROW(PHMM_EINVAL, "these mappings were not produced by phmm_generate_mappings");
+        double tot = 0.0;
+        for (double v : mp->read_logp) tot += v;
+        put_doubles(out_logp, mp->read_logp.data(), mp->R);
+        put_doubles(out_total, &tot, 1);
+    });
+}
 
 // Mappings::to_node_freqs (hint.rs:161-171): freq[v] = sum of linear probs over all lists
 int phmm_mappings_node_freqs(const phmm_mappings *mp, uint32_t n_nodes, double *out) {

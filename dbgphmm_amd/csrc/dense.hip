@@ -633,7 +633,7 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
     st = CallStats();
     const int W = plan.W;
     const size_t NW = (size_t)m->N * W;
-    const uint64_t limit = workspace_limit();
+    const uint64_t limit = table_budget(m->ws_tables.bytes);
 
     DenseArgs base{};
     fill_model_args(base, m);

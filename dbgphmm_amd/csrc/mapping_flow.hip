@@ -381,7 +381,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         else hb[gi] = hl[gi] - 1;
         pos_max = std::max(pos_max, hb[gi] & ~(1 << 30));
     }
-    DevBuf ctl, pbuf, mpool, mmeta;
+    DevBuf &ctl = m->ws_aux[3], &pbuf = m->ws_aux[4], &mpool = m->ws_aux[5], &mmeta = m->ws_aux[6];
     size_t cb = 0;
     auto carve = [&](size_t bytes) {
         cb = (cb + 255) / 256 * 256;
@@ -407,7 +407,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
                                      hipMemcpyHostToDevice, s));
         mpool.reserve(map_cap);
         mmeta.reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1));
-        HIP_CHECK(hipMemsetAsync(mmeta.p, 0, mmeta.bytes, s));
+        HIP_CHECK(hipMemsetAsync(mmeta.p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1), s));
         RecPool mp{};
         mp.base = mpool.as<uint8_t>();
         mp.cap = map_cap;
@@ -459,13 +459,19 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.candB_val = (double *)(cp + o_bv);
         ma.ratio_lin = mc.ratio_lin;
         ma.err = (uint32_t *)(cp + o_err);
+        LaunchTimer lt(timing_enabled());
         for (int pos = pos_max; pos >= 0; pos--) {
+            lt.begin();
             launch_bwd_step(W, a, pos);
+            lt.end();
             launch_post_collect_w(W, ma, pos);
             hipLaunchKernelGGL(emit_dense_map, dim3(lanes, 2), dim3(64), 0, s, ma, pos);
             st.launches[1]++;
         }
         HIP_CHECK(hipGetLastError());
+        st.ms[1] += lt.total_ms();
+        for (int gi = 0; gi < lanes; gi++)
+            if (hl[gi] > 0) st.cells[1] += (uint64_t)((hb[gi] & ~(1 << 30)) + 1) * m->N;
         std::vector<uint32_t> herr(lanes);
         HIP_CHECK(hipMemcpyAsync(herr.data(), cp + o_err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -525,6 +531,7 @@ void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappi
     mp->read_off = reads->off;
     mp->pos_off.assign(reads->total + 1, 0);
     mp->read_max_list.assign(reads->R, 0);
+    mp->read_logp = lf;
     uint64_t w = 0;
     for (uint64_t r = 0; r < reads->R; r++) {
         const uint64_t len = reads->off[r + 1] - reads->off[r];

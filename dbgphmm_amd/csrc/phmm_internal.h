@@ -31,6 +31,8 @@ struct Error {
 
 hipStream_t current_stream();
 uint64_t workspace_limit();
+// DP-table budget of a call on model buffers that already hold `owned` bytes
+uint64_t table_budget(size_t owned);
 
 // ---------------------------------------------------------------- device buffers
 struct DevBuf {
@@ -122,6 +124,7 @@ struct phmm_model {
     phmm::ModelDev dev;
     // grow-only workspaces
     phmm::DevBuf ws_tables, ws_misc, ws_out;
+    phmm::DevBuf ws_aux[16];  // per-call scratch kept across calls (no hipMalloc in the steady state)
 };
 
 struct phmm_reads {
@@ -141,6 +144,7 @@ struct phmm_mappings {
     std::vector<uint32_t> nodes;
     std::vector<double> logp;
     std::vector<uint32_t> read_max_list;  // [R] longest node list of each read
+    std::vector<double> read_logp;        // [R] ln P(read) of the forward pass that produced the mappings (may be empty)
     mutable phmm::DevBuf d_pos_off, d_nodes;
     mutable bool on_device = false;
 };
@@ -154,6 +158,36 @@ struct CallStats {
 };
 CallStats &stats();
 bool timing_enabled();
+
+// Per-launch HIP-event timing of one kernel class on the call's stream (bench.py's roofline):
+// an event pair brackets every launch, the elapsed times are summed after one final sync.
+struct LaunchTimer {
+    bool on;
+    std::vector<hipEvent_t> ev;
+    explicit LaunchTimer(bool on_) : on(on_) {}
+    ~LaunchTimer() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+    void begin() {
+        if (!on) return;
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventRecord(e, current_stream()));
+        ev.push_back(e);
+    }
+    void end() { begin(); }
+    double total_ms() {
+        if (!on || ev.empty()) return 0.0;
+        HIP_CHECK(hipEventSynchronize(ev.back()));
+        double t = 0.0;
+        for (size_t k = 0; k + 1 < ev.size(); k += 2) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            t += ms;
+        }
+        return t;
+    }
+};
 
 void model_build_host(phmm_model *m);    // CSR + logib
 void model_upload(phmm_model *m);        // closures + device arrays

@@ -336,7 +336,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     Plan plan = make_plan(m, reads, 0);
     const int W = plan.W;
     const size_t NW = (size_t)m->N * W;
-    const uint64_t limit = workspace_limit();
+    const uint64_t limit = table_budget(m->ws_tables.bytes);
     std::vector<double> lf(R, 0.0);
 
     DenseArgs base{};
@@ -347,8 +347,8 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     base.eall = 0;
     base.want_freq = 0;
 
-    DevBuf warm;  // per-chunk warm-up control arrays
-    DevBuf fpool, fpool_meta;  // forward table records (generate_mappings)
+    DevBuf &warm = m->ws_aux[0];  // per-chunk warm-up control arrays
+    DevBuf &fpool = m->ws_aux[1], &fpool_meta = m->ws_aux[2];  // forward table records (generate_mappings)
     int g0 = 0;
     while (g0 < plan.ng_total) {
         const uint32_t r0 = plan.order[(size_t)g0 * W];
@@ -431,8 +431,11 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
 
         // ---- dense warm-up with per-read switch decisions
         int pos = 0;
+        LaunchTimer lt(timing_enabled());
         for (;; pos++) {
+            lt.begin();
             launch_fwd_step(W, a, pos);  // column pos (if pos < Lc), d + totals maximum of column pos-1
+            lt.end();
             st.launches[0]++;
             if (pos >= 1) launch_col_count_w(W, wa, pos - 1);
             HIP_CHECK(hipMemsetAsync(wa.undecided, 0, sizeof(int), s));
@@ -443,6 +446,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             if (und == 0) break;
             if (pos >= Lc) PHMM_THROW(PHMM_EINTERNAL, "warm-up did not terminate");
         }
+        st.ms[0] += lt.total_ms();
         // reads that ended inside the warm-up: fe of their last (dense) column
         launch_fwd_finish(W, a);
         std::vector<int> hsw(lanes);
@@ -531,7 +535,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 if (sink) {
                     fpool.reserve(pool_cap);
                     fpool_meta.reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1) * 2);
-                    HIP_CHECK(hipMemsetAsync(fpool_meta.p, 0, fpool_meta.bytes, s));
+                    HIP_CHECK(hipMemsetAsync(fpool_meta.p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1) * 2, s));
                     fa.pool.base = fpool.as<uint8_t>();
                     fa.pool.cap = pool_cap;
                     fa.pool.top = fpool_meta.as<unsigned long long>();

@@ -96,6 +96,13 @@ class Mappings:
         g = int(self.reads.offsets[read]) + pos
         return lp[int(po[g]):int(po[g + 1])]
 
+    def read_logp(self, out_logp=None):
+        """ln P(read) of the forward pass that produced these mappings -> (total, per read)."""
+        lp = np.empty(len(self.reads)) if out_logp is None else out_logp
+        tot = np.empty(1)
+        _ffi.check(_ffi.lib().phmm_mappings_read_logp(self._h, _ptr(lp), _ptr(tot)))
+        return float(tot[0]), lp
+
     def to_node_freqs(self, n_nodes: int) -> np.ndarray:
         """Mappings::to_node_freqs (hint.rs:161-171)"""
         out = np.empty(n_nodes)

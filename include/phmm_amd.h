@@ -131,6 +131,10 @@ int phmm_mappings_export(const phmm_mappings *mp, uint64_t *pos_off, uint32_t *n
                          double *logp);
 /* Mappings::to_node_freqs, hint.rs:161-171 */
 int phmm_mappings_node_freqs(const phmm_mappings *mp, uint32_t n_nodes, double *out_freq);
+/* ln P(read) (forward `e` of the last table, table.rs:395-401) of the run_sparse_adaptive pass
+ * that produced `mp` in phmm_generate_mappings: PHMMOutput::to_full_prob_forward per read.
+ * out_logp[R] / out_total (their sum) may be NULL or device pointers. */
+int phmm_mappings_read_logp(const phmm_mappings *mp, double *out_logp, double *out_total);
 void phmm_mappings_destroy(phmm_mappings *mp);
 
 /* ---- read-set likelihood ------------------------------------------------------
