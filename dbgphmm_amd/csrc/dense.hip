@@ -122,43 +122,84 @@ __global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int p
     double vmax = 0.0, esum = 0.0, tmax = 0.0;
     const bool want_e = fin || (a.eall && have_prev);
     if (lb < a.nblk) {
-        const int kbase = lb * (a.npt * ROWS) + row;
+        // Each row of W lanes walks a RUN of npt consecutive node ids.  On a unitig run
+        // (NodeRec flag CHAIN_F: the closure of k is exactly k-1 .. k-6 with unit weights) the
+        // ancestors' values come from a register window that is refreshed by the node's own
+        // m, i loads -- 16 B read + 24 B written per cell, no closure traffic at all.
+        constexpr int H = CHAIN_HOPS;
+        const int kbase = lb * (a.npt * ROWS) + row * a.npt;
+        double wg[H];  // g = p_MD m + p_ID i of nodes k-1 .. k-H (prev column, rescaled)
+        double wm0 = 0.0, wi0 = 0.0;
+        int nvalid = 0;
+        const double pdd1 = lp.p_DD, pdd2 = pdd1 * pdd1, pdd3 = pdd2 * pdd1, pdd4 = pdd2 * pdd2;
+#pragma unroll
+        for (int h = 0; h < H; h++) wg[h] = 0.0;
+        const double c = lp.p_ID * ibs;  // p_MD*mb + p_ID*ib with mb = 0 (fmb)
+        const double cb = lp.p_IM * ibs;
         for (int j = 0; j < a.npt; j++) {
-            int k = kbase + j * ROWS;
+            int k = kbase + j;
             if (W == 64) k = __builtin_amdgcn_readfirstlane(k);
             if (k >= a.N) break;
             if (!(newcol || have_prev)) continue;
+            const NodeRec nr = a.nodes[k];
+            const size_t ik = (size_t)k * W + r;
             double mnew, inew = 0.0;
-            const double pe = a.emis[k] == x ? lp.p_match : lp.p_mismatch;
+            const double pe = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
             if (pos == 0) {
                 // f_init: mb = 1, everything else 0 (forward.rs:255-266)
-                mnew = pe * a.init[k] * lp.p_MM;
+                mnew = pe * nr.init * lp.p_MM;
             } else {
-                double m1 = 0.0, i1 = 0.0, dacc = 0.0, tacc = 0.0;
-                const uint32_t o0 = a.fc_off[k], o1 = a.fc_off[k + 1];
-                for (uint32_t q = o0; q < o1; q++) {
-                    const FwdEntry en = a.fc[q];
-                    const size_t ix = (size_t)en.node * W + r;
-                    const double vm = pm[ix] * sc, vi = pi[ix] * sc;
-                    const double gg = lp.p_MD * vm + lp.p_ID * vi;
-                    m1 += en.w1 * vm;
-                    i1 += en.w1 * vi;
-                    dacc += en.wD * gg;
-                    tacc += en.wT * gg;
-                }
-                const size_t ik = (size_t)k * W + r;
                 const double om = pm[ik] * sc, oi = pi[ik] * sc;
-                const double c = lp.p_ID * ibs;  // p_MD*mb + p_ID*ib with mb = 0 (fmb)
-                const double dprev = dacc + c * a.dinit[k];
-                const double td = tacc + c * a.tdinit[k];
+                double m1, i1, dacc, tacc;
+                if (nr.flags & CHAIN_F) {
+                    if (nvalid < H) {
+                        // run start: fill the window from memory
+#pragma unroll
+                        for (int h = 0; h < H; h++) {
+                            const size_t ix = (size_t)(k - 1 - h) * W + r;
+                            const double vm = pm[ix] * sc, vi = pi[ix] * sc;
+                            wg[h] = lp.p_MD * vm + lp.p_ID * vi;
+                            if (h == 0) {
+                                wm0 = vm;
+                                wi0 = vi;
+                            }
+                        }
+                        nvalid = H;
+                    }
+                    m1 = wm0;
+                    i1 = wi0;
+                    dacc = wg[0] + pdd1 * wg[1] + pdd2 * wg[2] + pdd3 * wg[3] + pdd4 * wg[4];
+                    tacc = wg[1] + pdd1 * wg[2] + pdd2 * wg[3] + pdd3 * wg[4] + pdd4 * wg[5];
+                } else {
+                    m1 = i1 = dacc = tacc = 0.0;
+                    const uint32_t o0 = a.fc_off[k], o1 = a.fc_off[k + 1];
+                    for (uint32_t q = o0; q < o1; q++) {
+                        const FwdEntry en = a.fc[q];
+                        const size_t ix = (size_t)en.node * W + r;
+                        const double vm = pm[ix] * sc, vi = pi[ix] * sc;
+                        const double gg = lp.p_MD * vm + lp.p_ID * vi;
+                        m1 += en.w1 * vm;
+                        i1 += en.w1 * vi;
+                        dacc += en.wD * gg;
+                        tacc += en.wT * gg;
+                    }
+                }
+                const double dprev = dacc + c * nr.dinit;
+                const double td = tacc + c * nr.tdinit;
                 pd[ik] = dprev * isc;  // stored in column pos-1's own exponent
-                mnew = pe * (lp.p_MM * m1 + lp.p_IM * i1 + lp.p_DM * td + a.init[k] * (lp.p_IM * ibs));
+                mnew = pe * (lp.p_MM * m1 + lp.p_IM * i1 + lp.p_DM * td + nr.init * cb);
                 inew = lp.p_random * (lp.p_MI * om + lp.p_II * oi + lp.p_DI * dprev);
                 if (want_e) esum += om + oi + dprev;
                 tmax = fmax(tmax, om + oi + dprev);
+                // slide the window: this node becomes "k-1" of the next one
+#pragma unroll
+                for (int h = H - 1; h >= 1; h--) wg[h] = wg[h - 1];
+                wg[0] = lp.p_MD * om + lp.p_ID * oi;
+                wm0 = om;
+                wi0 = oi;
+                nvalid = nvalid < H ? nvalid + 1 : H;
             }
             if (newcol) {
-                const size_t ik = (size_t)k * W + r;
                 cm_[ik] = mnew;
                 ci_[ik] = inew;
                 vmax = fmax(vmax, fmax(mnew, inew));
@@ -323,31 +364,72 @@ __global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int p
     double *Pa = a.want_map ? a.Pa + (size_t)g * NW : nullptr;
     double *Pb = a.want_map ? a.Pb + (size_t)g * NW : nullptr;
     if (lb < a.nblk) {
-        const int kbase = lb * (a.npt * ROWS) + row;
-        for (int j = 0; j < a.npt; j++) {
-            int v = kbase + j * ROWS;
+        // Rows walk their run of npt consecutive nodes in DECREASING order; on a unitig run
+        // (CHAIN_B: the descendants within 6 hops are v+1 .. v+6 with unit weights) the values
+        // h[u] = e_u(x) m'[u], q[u] = p_r i'[u] come from a register window fed by own loads.
+        constexpr int H = CHAIN_HOPS;
+        const int kbase = lb * (a.npt * ROWS) + row * a.npt;
+        double wh[H], wq[H];  // h, q of nodes v+1 .. v+H (column pos+1, rescaled)
+        int nvalid = 0;
+        const double pdd1 = lp.p_DD, pdd2 = pdd1 * pdd1, pdd3 = pdd2 * pdd1, pdd4 = pdd2 * pdd2;
+#pragma unroll
+        for (int h = 0; h < H; h++) wh[h] = wq[h] = 0.0;
+        for (int j = a.npt - 1; j >= 0; j--) {
+            int v = kbase + j;
             if (W == 64) v = __builtin_amdgcn_readfirstlane(v);
-            if (v >= a.N) break;
+            if (v >= a.N) continue;
             double contrib = 0.0;
             if (live) {
-                double a1 = 0.0, ad = 0.0, at = 0.0, qd = 0.0, qt = 0.0;
-                const uint32_t o0 = a.bc_off[v], o1 = a.bc_off[v + 1];
-                for (uint32_t q = o0; q < o1; q++) {
-                    const BwdEntry en = a.bc[q];
-                    const size_t ix = (size_t)en.node * W + r;
-                    const double mu = first ? lp.p_end : nm[ix] * sc;
-                    const double iu = first ? lp.p_end : ni[ix] * sc;
-                    const double h = ((uint8_t)en.emis == x ? lp.p_match : lp.p_mismatch) * mu;
-                    const double qq = lp.p_random * iu;
-                    a1 += en.c1 * h;
-                    ad += en.cAd * h;
-                    at += en.cAt * h;
-                    qd += en.cQd * qq;
-                    qt += en.cAd * qq;
-                }
+                const NodeRec nr = a.nodes[v];
                 const size_t iv = (size_t)v * W + r;
                 const double m0 = first ? lp.p_end : nm[iv] * sc;
                 const double q0 = lp.p_random * (first ? lp.p_end : ni[iv] * sc);
+                const double ev = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
+                double a1, ad, at, qd, qt;
+                if (nr.flags & CHAIN_B) {
+                    if (nvalid < H) {
+#pragma unroll
+                        for (int h = 0; h < H; h++) {
+                            const int u = v + 1 + h;
+                            const size_t ix = (size_t)u * W + r;
+                            const double mu = first ? lp.p_end : nm[ix] * sc;
+                            const double iu = first ? lp.p_end : ni[ix] * sc;
+                            wh[h] = ((uint8_t)a.nodes[u].emis == x ? lp.p_match : lp.p_mismatch) * mu;
+                            wq[h] = lp.p_random * iu;
+                        }
+                        nvalid = H;
+                    }
+                    a1 = wh[0];
+                    ad = wh[0] + pdd1 * wh[1] + pdd2 * wh[2] + pdd3 * wh[3] + pdd4 * wh[4];
+                    at = wh[1] + pdd1 * wh[2] + pdd2 * wh[3] + pdd3 * wh[4] + pdd4 * wh[5];
+                    qd = pdd1 * wq[0] + pdd2 * wq[1] + pdd3 * wq[2] + pdd4 * wq[3];
+                    qt = wq[0] + pdd1 * wq[1] + pdd2 * wq[2] + pdd3 * wq[3] + pdd4 * wq[4];
+                } else {
+                    a1 = ad = at = qd = qt = 0.0;
+                    const uint32_t o0 = a.bc_off[v], o1 = a.bc_off[v + 1];
+                    for (uint32_t q = o0; q < o1; q++) {
+                        const BwdEntry en = a.bc[q];
+                        const size_t ix = (size_t)en.node * W + r;
+                        const double mu = first ? lp.p_end : nm[ix] * sc;
+                        const double iu = first ? lp.p_end : ni[ix] * sc;
+                        const double h = ((uint8_t)en.emis == x ? lp.p_match : lp.p_mismatch) * mu;
+                        const double qq = lp.p_random * iu;
+                        a1 += en.c1 * h;
+                        ad += en.cAd * h;
+                        at += en.cAt * h;
+                        qd += en.cQd * qq;
+                        qt += en.cAd * qq;
+                    }
+                }
+                // slide the window: this node becomes "v+1" of the next (lower) one
+#pragma unroll
+                for (int h = H - 1; h >= 1; h--) {
+                    wh[h] = wh[h - 1];
+                    wq[h] = wq[h - 1];
+                }
+                wh[0] = ev * m0;
+                wq[0] = q0;
+                nvalid = nvalid < H ? nvalid + 1 : H;
                 const double d = lp.p_DM * ad + lp.p_DI * (q0 + qd);
                 const double td = lp.p_DM * at + lp.p_DI * qt;
                 const double m = lp.p_MM * a1 + lp.p_MD * td + lp.p_MI * q0;
@@ -356,8 +438,7 @@ __global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int p
                 oi[iv] = i;
                 if (od) od[iv] = d;
                 vmax = fmax(vmax, fmax(m, i));
-                const double ev = a.emis[v] == x ? lp.p_match : lp.p_mismatch;
-                const double in = a.init[v];
+                const double in = nr.init;
                 s1 += in * (lp.p_MM * ev * m0 + lp.p_MD * d);
                 s2 += in * (lp.p_IM * ev * m0 + lp.p_ID * d);
                 double c1 = 0.0, c2 = 0.0;
@@ -602,6 +683,7 @@ void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &
 void fill_model_args(DenseArgs &a, const phmm_model *m) {
     const ModelDev &d = m->dev;
     a.N = (int)m->N;
+    a.nodes = d.nodes.as<NodeRec>();
     a.emis = d.emis.as<uint8_t>();
     a.init = d.init.as<double>();
     a.dinit = d.dinit.as<double>();

@@ -14,6 +14,7 @@ static constexpr int BLOCK = 256;
 struct DenseArgs {
     int N, ng, Lc, nblk, npt;
     // model
+    const NodeRec *nodes;
     const uint8_t *emis;
     const double *init, *dinit, *tdinit;
     const uint32_t *fc_off;

@@ -121,6 +121,8 @@ void model_upload(phmm_model *m) {
     bc.reserve((size_t)N * 7);
     std::vector<FwdEntry> tmpf;
     std::vector<BwdEntry> tmpb;
+    std::vector<NodeRec> nodes(N);
+    const bool chain_ok = G == 4 && H == CHAIN_HOPS;
     for (uint32_t k = 0; k < N; k++) {
         tmpf.clear();
         double di = ilin[k], tdi = 0.0;
@@ -143,6 +145,22 @@ void model_upload(phmm_model *m) {
                      });
         dinit[k] = di;
         tdinit[k] = tdi;
+        uint32_t flags = 0;
+        // unitig run: ancestors are exactly k-1 .. k-H, every path weight 1
+        if (chain_ok && k >= (uint32_t)H && tmpf.size() == (size_t)H) {
+            bool ok = true;
+            for (int h = 1; h <= H && ok; h++) {
+                bool found = false;
+                for (const auto &e : tmpf)
+                    if (e.node == k - (uint32_t)h) {
+                        found = e.w1 == (h == 1 ? 1.0 : 0.0) && e.wD == (h <= G + 1 ? pdd[h - 1] : 0.0) &&
+                                e.wT == (h >= 2 ? pdd[h - 2] : 0.0);
+                        break;
+                    }
+                ok = found;
+            }
+            if (ok) flags |= CHAIN_F;
+        }
         fc.insert(fc.end(), tmpf.begin(), tmpf.end());
         fc_off[k + 1] = (uint32_t)fc.size();
 
@@ -164,6 +182,21 @@ void model_upload(phmm_model *m) {
                              }
                          tmpb.push_back(BwdEntry{u, m->emission[u], c1, cAd, cAt, cQd});
                      });
+        if (chain_ok && (uint64_t)k + H < N && tmpb.size() == (size_t)H) {
+            bool ok = true;
+            for (int h = 1; h <= H && ok; h++) {
+                bool found = false;
+                for (const auto &e : tmpb)
+                    if (e.node == k + (uint32_t)h) {
+                        found = e.c1 == (h == 1 ? 1.0 : 0.0) && e.cAd == (h <= G + 1 ? pdd[h - 1] : 0.0) &&
+                                e.cAt == (h >= 2 ? pdd[h - 2] : 0.0) && e.cQd == (h <= G ? pdd[h] : 0.0);
+                        break;
+                    }
+                ok = found;
+            }
+            if (ok) flags |= CHAIN_B;
+        }
+        nodes[k] = NodeRec{ilin[k], dinit[k], tdinit[k], m->emission[k], flags};
         bc.insert(bc.end(), tmpb.begin(), tmpb.end());
         bc_off[k + 1] = (uint32_t)bc.size();
     }
@@ -171,6 +204,7 @@ void model_upload(phmm_model *m) {
     ModelDev &d = m->dev;
     d.N = N;
     d.E = E;
+    d.nodes.upload(nodes.data(), sizeof(NodeRec) * N);
     d.emis.upload(m->emission.data(), N);
     d.init.upload(ilin.data(), sizeof(double) * N);
     d.dinit.upload(dinit.data(), sizeof(double) * N);

@@ -92,8 +92,21 @@ struct BwdEntry {
     double c1, cAd, cAt, cQd;
 };
 
+// Per-node record of the dense kernels (one 32-byte scalar load per node).
+//   CHAIN_F: the ancestor closure of k is exactly k-1 .. k-CHAIN_HOPS with unit weights
+//   CHAIN_B: the descendant closure of k is exactly k+1 .. k+CHAIN_HOPS with unit weights
+// (k sits on a unitig run whose node ids are consecutive; set only when n_max_gaps == 4)
+struct NodeRec {
+    double init, dinit, tdinit;
+    uint32_t emis;
+    uint32_t flags;
+};
+static constexpr uint32_t CHAIN_F = 1u, CHAIN_B = 2u;
+static constexpr int CHAIN_HOPS = 6;
+
 struct ModelDev {
     uint32_t N = 0, E = 0;
+    DevBuf nodes;            // NodeRec[N]
     DevBuf emis;             // u8[N]
     DevBuf init;             // f64[N] linear
     DevBuf dinit, tdinit;    // f64[N]

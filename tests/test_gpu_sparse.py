@@ -150,6 +150,10 @@ def _compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6):
             assert ka == kb, (i, gn, gl, on, ol)
             # (nodes with equal probability -- e.g. the two haplotype copies of a k-mer -- may swap)
             assert np.max(np.abs(gl[:ka] - ol[:kb]), initial=0.0) < tol, (i, gl, ol)
+            if a1 - a0 == 400:
+                # list capped at MAX_ACTIVE_NODES: which of the nodes that TIE with the 400th value are
+                # kept is arbitrary (sparsevec tie order is unpinned); compare strictly above the cut
+                ka = kb = int((gl > gl[-1] + 1e-9).sum())
             assert sorted(gn[:ka].tolist()) == sorted(on[:kb].tolist()), (i, gn, on)
             od = dict(zip(on[:kb].tolist(), ol[:kb].tolist()))
             assert all(abs(od[n] - l) < tol for n, l in zip(gn[:ka].tolist(), gl[:ka].tolist())), (i, gn, gl, on, ol)
@@ -185,7 +189,10 @@ def test_generate_mappings_matches_oracle(gpu_lib, oracle, cfg):
     mp, nf = gm.generate_mappings(rc, None, True)
     omp, onf = om.generate_mappings(reads, None, True, n_threads=8)
     _compare_mappings(reads, mp.arrays(), omp)
-    assert np.max(np.abs(nf - onf)) < 1e-6
+    if np.diff(mp.arrays()[0].astype(np.int64)).max() < 400:
+        assert np.max(np.abs(nf - onf)) < 1e-6
+    else:  # a capped list keeps an arbitrary subset of the nodes tied at the cut (see _compare_mappings)
+        assert abs(nf.sum() - onf.sum()) < 1e-6
     assert np.max(np.abs(mp.to_node_freqs(arrays.n_nodes) - nf)) < 1e-12
     # the mappings drive the hinted likelihood (hmmv2/tests/dbg.rs:85-114): 1e-4 on the total
     # (reads of a few bases are left out: their first lists hold 400 of the N nodes inside the ratio)
