@@ -1,5 +1,7 @@
 // extern "C" surface of libphmm_amd.so (include/phmm_amd.h).  Argument validation mirrors
 // the reference's asserts/panics; nothing throws across the ABI.
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
@@ -27,6 +29,17 @@ uint64_t workspace_limit() {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)16 << 30;
     return (uint64_t)(0.8 * (double)fr);
+}
+
+void trace(const char *tag) {
+    static const bool on = std::getenv("PHMM_TRACE") != nullptr;
+    if (!on) return;
+    static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    (void)hipStreamSynchronize(g_stream);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[phmm trace] %-28s %8.2f ms\n", tag,
+                 std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
 }
 
 uint64_t table_budget(size_t owned) {

@@ -136,6 +136,17 @@ __global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int p
         for (int h = 0; h < H; h++) wg[h] = 0.0;
         const double c = lp.p_ID * ibs;  // p_MD*mb + p_ID*ib with mb = 0 (fmb)
         const double cb = lp.p_IM * ibs;
+        // software pipeline: the own loads of node k+1 are issued before node k is computed
+        const bool ld = have_prev && pos >= 1;
+        double nx_m = 0.0, nx_i = 0.0;
+        {
+            int k0 = kbase;
+            if (W == 64) k0 = __builtin_amdgcn_readfirstlane(k0);
+            if (ld && k0 < a.N) {
+                nx_m = pm[(size_t)k0 * W + r];
+                nx_i = pi[(size_t)k0 * W + r];
+            }
+        }
         for (int j = 0; j < a.npt; j++) {
             int k = kbase + j;
             if (W == 64) k = __builtin_amdgcn_readfirstlane(k);
@@ -143,13 +154,18 @@ __global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int p
             if (!(newcol || have_prev)) continue;
             const NodeRec nr = a.nodes[k];
             const size_t ik = (size_t)k * W + r;
+            const double cur_m = nx_m, cur_i = nx_i;
+            if (ld && j + 1 < a.npt && k + 1 < a.N) {
+                nx_m = pm[ik + W];
+                nx_i = pi[ik + W];
+            }
             double mnew, inew = 0.0;
             const double pe = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
             if (pos == 0) {
                 // f_init: mb = 1, everything else 0 (forward.rs:255-266)
                 mnew = pe * nr.init * lp.p_MM;
             } else {
-                const double om = pm[ik] * sc, oi = pi[ik] * sc;
+                const double om = cur_m * sc, oi = cur_i * sc;
                 double m1, i1, dacc, tacc;
                 if (nr.flags & CHAIN_F) {
                     if (nvalid < H) {
@@ -374,6 +390,27 @@ __global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int p
         const double pdd1 = lp.p_DD, pdd2 = pdd1 * pdd1, pdd3 = pdd2 * pdd1, pdd4 = pdd2 * pdd2;
 #pragma unroll
         for (int h = 0; h < H; h++) wh[h] = wq[h] = 0.0;
+        // software pipeline: own B values and the F column of node v-1 are loaded before node v
+        // is computed
+        const bool ldb = live && !first, ldf = live && wgt != 0.0;
+        double nx_m = 0.0, nx_i = 0.0, nx_fm = 0.0, nx_fi = 0.0, nx_fd = 0.0;
+        {
+            int v0 = kbase + a.npt - 1;
+            if (v0 >= a.N) v0 = a.N - 1;
+            if (W == 64) v0 = __builtin_amdgcn_readfirstlane(v0);
+            if (v0 >= kbase) {
+                const size_t i0 = (size_t)v0 * W + r;
+                if (ldb) {
+                    nx_m = nm[i0];
+                    nx_i = ni[i0];
+                }
+                if (ldf) {
+                    nx_fm = fm[i0];
+                    nx_fi = fi[i0];
+                    nx_fd = fd[i0];
+                }
+            }
+        }
         for (int j = a.npt - 1; j >= 0; j--) {
             int v = kbase + j;
             if (W == 64) v = __builtin_amdgcn_readfirstlane(v);
@@ -382,8 +419,20 @@ __global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int p
             if (live) {
                 const NodeRec nr = a.nodes[v];
                 const size_t iv = (size_t)v * W + r;
-                const double m0 = first ? lp.p_end : nm[iv] * sc;
-                const double q0 = lp.p_random * (first ? lp.p_end : ni[iv] * sc);
+                const double cur_m = nx_m, cur_i = nx_i, cur_fm = nx_fm, cur_fi = nx_fi, cur_fd = nx_fd;
+                if (j > 0) {
+                    if (ldb) {
+                        nx_m = nm[iv - W];
+                        nx_i = ni[iv - W];
+                    }
+                    if (ldf) {
+                        nx_fm = fm[iv - W];
+                        nx_fi = fi[iv - W];
+                        nx_fd = fd[iv - W];
+                    }
+                }
+                const double m0 = first ? lp.p_end : cur_m * sc;
+                const double q0 = lp.p_random * (first ? lp.p_end : cur_i * sc);
                 const double ev = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
                 double a1, ad, at, qd, qt;
                 if (nr.flags & CHAIN_B) {
@@ -442,7 +491,7 @@ __global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int p
                 s1 += in * (lp.p_MM * ev * m0 + lp.p_MD * d);
                 s2 += in * (lp.p_IM * ev * m0 + lp.p_ID * d);
                 double c1 = 0.0, c2 = 0.0;
-                if (wgt != 0.0) c1 = wgt * (fm[iv] * m + fi[iv] * i + fd[iv] * d);
+                if (wgt != 0.0) c1 = wgt * (cur_fm * m + cur_fi * i + cur_fd * d);
                 if (wgt2 != 0.0) c2 = wgt2 * (gm[iv] + gi[iv] + gd[iv]);
                 contrib = c1 + c2;
                 if (a.want_map) {
@@ -640,9 +689,13 @@ Plan make_plan(const phmm_model *m, const phmm_reads *reads, int forced_w) {
     p.W = forced_w > 0 ? forced_w : choose_width(R);
     p.ng_total = (int)((R + p.W - 1) / p.W);
     const int rows = BLOCK / p.W;
-    // nodes per thread: keep the per-column partial count (blocks) <= ~2048
+    // run length (consecutive nodes walked by one row of W lanes): as long as the launch still
+    // has >= ~8192 waves (the window fill at a run start costs 12 loads, a node on the run 2),
+    // and long enough that a column has <= ~4096 per-block partials
     int npt = 4;
-    while ((int64_t)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows)) > 2048 && npt < 64) npt *= 2;
+    const double lanes_total = (double)m->N * (double)(p.ng_total * p.W);
+    while (npt < 64 && lanes_total / (npt * 2) >= 524288.0) npt *= 2;
+    while ((int64_t)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows)) > 4096 && npt < 64) npt *= 2;
     p.npt = npt;
     p.nblk = (int)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows));
     p.nblk8 = (p.nblk + 7) / 8 * 8;

@@ -446,6 +446,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             HIP_CHECK(hipGetLastError());
             st.launches[3]++;
         }
+        trace("  sparse backward");
         DenseMapArgs ma{};
         ma.d = a;
         ma.W = W;
@@ -481,6 +482,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             else if (herr[gi]) PHMM_THROW(PHMM_EINTERNAL, "mapping backward error " + std::to_string(herr[gi]));
         }
         if (!pool_full) {
+            trace("  dense backward+collect");
             // gather the records
             unsigned long long used = 0;
             HIP_CHECK(hipMemcpy(&used, mp.top, sizeof(used), hipMemcpyDeviceToHost));
@@ -509,6 +511,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
                     lg.insert(lg.end(), lps, lps + n);
                 }
             }
+            trace("  gather+assemble");
             break;
         }
         if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "mapping pool keeps overflowing");

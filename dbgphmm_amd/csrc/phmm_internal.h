@@ -202,6 +202,9 @@ struct LaunchTimer {
     }
 };
 
+// PHMM_TRACE=1: print host-side phase times (syncs the stream; diagnostics only)
+void trace(const char *tag);
+
 void model_build_host(phmm_model *m);    // CSR + logib
 void model_upload(phmm_model *m);        // closures + device arrays
 

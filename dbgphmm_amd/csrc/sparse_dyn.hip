@@ -389,6 +389,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         HIP_CHECK(hipMemsetAsync(wp + o_sw, 0xff, sizeof(int) * lanes, s));  // sw = -1
 
         // host staging (the full-length transposed bases are needed by the sparse kernel)
+        trace("chunk setup");
         std::vector<uint8_t> hb((size_t)ngc * Lc * W, 0xff), hbf((size_t)ngc * Lfull * W, 0xff);
         std::vector<int> hl((size_t)lanes, 0);
         uint64_t dense_cells = 0;
@@ -429,6 +430,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         wa.n_warmup = (int)prm.n_warmup;
         wa.threshold = (int)prm.warmup_threshold;
 
+        trace("staging+upload");
         // ---- dense warm-up with per-read switch decisions
         int pos = 0;
         LaunchTimer lt(timing_enabled());
@@ -447,6 +449,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             if (pos >= Lc) PHMM_THROW(PHMM_EINTERNAL, "warm-up did not terminate");
         }
         st.ms[0] += lt.total_ms();
+        trace("dense warm-up");
         // reads that ended inside the warm-up: fe of their last (dense) column
         launch_fwd_finish(W, a);
         std::vector<int> hsw(lanes);
@@ -499,6 +502,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             HIP_CHECK(hipStreamSynchronize(s));
         }
 
+        trace("switch bookkeeping");
         // ---- sparse continuation, one wave per read
         std::vector<double> slp(lanes, 0.0);
         if (!sparse_lanes.empty()) {
@@ -583,7 +587,9 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 mc.d_logp_sparse = fa.out_logp;
                 mc.cand_node = wa.cand_node;
                 mc.cand_tot = wa.cand_tot;
+                trace("sparse forward");
                 mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
+                trace("mapping backward total");
             }
         } else if (sink) {
             // every read of the chunk ended inside the dense warm-up
