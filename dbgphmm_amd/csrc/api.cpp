@@ -71,6 +71,21 @@ void put_doubles(double *dst, const double *src, size_t n) {
     }
 }
 
+// device-resident mappings -> host vectors (first host access only)
+void mappings_materialize_host(const phmm_mappings *cmp) {
+    if (cmp->host_valid) return;
+    auto *mp = const_cast<phmm_mappings *>(cmp);
+    mp->pos_off.resize(mp->total_pos + 1);
+    mp->nodes.resize(mp->total_entries);
+    mp->logp.resize(mp->total_entries);
+    HIP_CHECK(hipMemcpy(mp->pos_off.data(), mp->d_pos_off.p, sizeof(uint64_t) * (mp->total_pos + 1), hipMemcpyDeviceToHost));
+    if (mp->total_entries) {
+        HIP_CHECK(hipMemcpy(mp->nodes.data(), mp->d_nodes.p, sizeof(uint32_t) * mp->total_entries, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(mp->logp.data(), mp->d_logp.p, sizeof(double) * mp->total_entries, hipMemcpyDeviceToHost));
+    }
+    mp->host_valid = true;
+}
+
 template <class F> static int guarded(F &&f) {
     try {
         f();
@@ -310,6 +325,7 @@ int phmm_mappings_create(const phmm_reads *reads, const uint64_t *pos_off, const
         mp->nodes.assign(nodes, nodes + te);
         if (logp) mp->logp.assign(logp, logp + te);
         else mp->logp.assign(te, 0.0);
+        mp->total_entries = te;
         mp->read_max_list.assign(reads->R, 0);
         for (uint64_t r = 0; r < reads->R; r++)
             for (uint64_t i = reads->off[r]; i < reads->off[r + 1]; i++)
@@ -320,10 +336,11 @@ int phmm_mappings_create(const phmm_reads *reads, const uint64_t *pos_off, const
     return rc;
 }
 uint64_t phmm_mappings_total_positions(const phmm_mappings *mp) { return mp ? mp->total_pos : 0; }
-uint64_t phmm_mappings_total_entries(const phmm_mappings *mp) { return mp ? mp->nodes.size() : 0; }
+uint64_t phmm_mappings_total_entries(const phmm_mappings *mp) { return mp ? mp->total_entries : 0; }
 int phmm_mappings_export(const phmm_mappings *mp, uint64_t *pos_off, uint32_t *nodes, double *logp) {
     return guarded([&] {
         if (!mp) PHMM_THROW(PHMM_EINVAL, "NULL mappings");
+        mappings_materialize_host(mp);
         if (pos_off) std::memcpy(pos_off, mp->pos_off.data(), mp->pos_off.size() * sizeof(uint64_t));
         if (nodes) std::memcpy(nodes, mp->nodes.data(), mp->nodes.size() * sizeof(uint32_t));
         if (logp) std::memcpy(logp, mp->logp.data(), mp->logp.size() * sizeof(double));
@@ -347,6 +364,7 @@ int phmm_mappings_read_logp(const phmm_mappings *mp, double *out_logp, double *o
 int phmm_mappings_node_freqs(const phmm_mappings *mp, uint32_t n_nodes, double *out) {
     return guarded([&] {
         if (!mp || !out) PHMM_THROW(PHMM_EINVAL, "NULL argument");
+        mappings_materialize_host(mp);
         std::vector<double> f(n_nodes, 0.0);
         for (size_t a = 0; a < mp->nodes.size(); a++) {
             if (mp->nodes[a] >= n_nodes) PHMM_THROW(PHMM_EINVAL, "mapping node out of range");
@@ -359,6 +377,7 @@ int phmm_mappings_node_freqs(const phmm_mappings *mp, uint32_t n_nodes, double *
 static void check_mapping_nodes(const phmm_model *m, const phmm_mappings *mp, const phmm_reads *reads) {
     if (mp->R != reads->R || mp->total_pos != reads->total || mp->read_off != reads->off)
         PHMM_THROW(PHMM_EINVAL, "mappings were built for a different read set");
+    if (mp->trusted) return;
     for (uint32_t v : mp->nodes)
         if (v >= m->N) PHMM_THROW(PHMM_EINVAL, "mapping node out of range");
 }

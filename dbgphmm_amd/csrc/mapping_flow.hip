@@ -13,6 +13,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
+
+#include <hipcub/hipcub.hpp>
 
 #include "sparse_dyn.h"
 
@@ -103,7 +106,8 @@ struct SparseBwdArgs {
     const int *sw;
     const uint8_t *bases;
     RecPool fpool, mpool;
-    const uint64_t *lane_pos0;
+    const uint64_t *lane_pos0;  // forward-record position base of each lane (chunk local)
+    const uint64_t *map_pos0;   // global read position base of each lane (mapping records)
     const uint32_t *lanes;
     double ratio_lin;
     uint32_t *err;
@@ -122,6 +126,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
     const int len = a.d.len[gi];
     const int s0 = a.sw[gi];
     const uint64_t p0 = a.lane_pos0[gi];
+    const uint64_t q0 = a.map_pos0[gi];
     const double logP = a.d.logPf[gi];
     const LinParams &lp = a.M.lp;
     uint32_t err = 0;
@@ -132,7 +137,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
         const double w = ok ? exp((double)fr.E * SP_LN2 - logP) * lp.p_end : 0.0;
         for (int j = lane; j < fr.n; j += 64) val[j] = w * (fr.m[j] + fr.i[j] + fr.d[j]);
         __syncthreads();
-        if (!emit_mapping<CAP>(a.mpool, p0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
+        if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
             err |= SP_ERR_POOL;
     }
     int have_cols = 0;
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             val[j] = bs >= 0 ? w * (fr.m[j] * cur.m[bs] + fr.i[j] * cur.i[bs] + fr.d[j] * cur.d[bs]) : 0.0;
         }
         __syncthreads();
-        if (!emit_mapping<CAP>(a.mpool, p0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
+        if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
             err |= SP_ERR_POOL;
     }
     // hand B.tables[s0+1] to the dense backward kernel: dense column (zeros elsewhere = the
@@ -255,27 +260,47 @@ __global__ void __launch_bounds__(BLOCK) post_collect(const DenseMapArgs ma, con
 }
 
 // More than 400 nodes inside the ratio: keep the 400 best of the column (ties: lowest node id).
-__device__ int wave_top_from_column(const double *col, int stride, int N, double thr, double vmax, uint32_t *ids,
-                                    double *val) {
-    const int lane = threadIdx.x;
-    unsigned long long lo = (unsigned long long)__double_as_longlong(thr), hi = (unsigned long long)__double_as_longlong(vmax);
-    while (lo < hi) {  // largest T with count(v >= T) >= KMAX
-        const unsigned long long mid = lo + (hi - lo + 1ull) / 2ull;
-        int c = 0;
-        for (int k = lane; k < N; k += 64) {
-            const double v = col[(size_t)k * stride];
-            c += (v > thr && (unsigned long long)__double_as_longlong(v) >= mid) ? 1 : 0;
-        }
-        c = wave_isum(c);
-        if (c >= KMAX) lo = mid;
-        else hi = mid - 1ull;
+// One 256-thread block: 8-bit radix select of the 400th-largest bit pattern (positive doubles
+// order like integers), then an ordered collect (everything above it, then ties in node order).
+__device__ int block_top_from_column(const double *col, int stride, int N, double thr, uint32_t *ids, double *val) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_k, s_wcnt[BLOCK / 64], s_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        s_prefix = 0ull;
+        s_k = KMAX;
     }
-    const unsigned long long T = lo;
-    int n = 0;
-    // first everything above T, then ties in node order until the list is full
+    __syncthreads();
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        for (int k = tid; k < N; k += BLOCK) {
+            const double v = col[(size_t)k * stride];
+            if (!(v > thr)) continue;
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+            if (shift < 56 && (b >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+            atomicAdd(&hist[(b >> shift) & 255ull], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int k = s_k, d = 255;
+            for (; d > 0; d--) {
+                if ((int)hist[d] >= k) break;
+                k -= (int)hist[d];
+            }
+            s_k = k;
+            s_prefix = prefix | ((unsigned long long)d << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned long long T = s_prefix;  // bit pattern of the 400th-largest value (or the smallest one)
+    if (tid == 0) s_n = 0;
+    __syncthreads();
     for (int pass = 0; pass < 2; pass++)
-        for (int base = 0; base < N && n < KMAX; base += 64) {
-            const int k = base + lane;
+        for (int base = 0; base < N; base += BLOCK) {
+            const int k = base + tid;
             double v = 0.0;
             bool take = false;
             if (k < N) {
@@ -284,19 +309,29 @@ __device__ int wave_top_from_column(const double *col, int stride, int N, double
                 take = v > thr && (pass == 0 ? b > T : b == T);
             }
             const unsigned long long mk = __ballot(take);
-            const int p = n + __popcll(mk & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wcnt[wave] = __popcll(mk);
+            __syncthreads();
+            int p = s_n + __popcll(mk & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; w++) p += s_wcnt[w];
             if (take && p < KMAX) {
                 ids[p] = (uint32_t)k;
                 val[p] = v;
             }
-            n += __popcll(mk);
+            __syncthreads();
+            if (tid == 0) {
+                int t = s_n;
+                for (int w = 0; w < BLOCK / 64; w++) t += s_wcnt[w];
+                s_n = t;
+            }
+            __syncthreads();
+            if (s_n >= KMAX) break;
         }
     __syncthreads();
-    return n < KMAX ? n : KMAX;
+    return s_n < KMAX ? s_n : KMAX;
 }
 
 // one wave per (lane, which): sort the collected nodes and write the mapping record
-__global__ void __launch_bounds__(64) emit_dense_map(const DenseMapArgs ma, const int pos) {
+__global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, const int pos) {
     __shared__ uint32_t ids[KMAX];
     __shared__ double val[KMAX];
     __shared__ uint16_t order[KMAX];
@@ -318,16 +353,17 @@ __global__ void __launch_bounds__(64) emit_dense_map(const DenseMapArgs ma, cons
     if (c > KMAX) {
         const double *P = (which == 0 ? a.Pa : a.Pb) + (size_t)g * a.N * ma.W + r;
         const double vmax = __longlong_as_double((long long)a.pmax[((size_t)g * (a.Lc + 1) + mi) * ma.W + r]);
-        n = wave_top_from_column(P, ma.W, a.N, vmax * ma.ratio_lin, vmax, ids, val);
+        n = block_top_from_column(P, ma.W, a.N, vmax * ma.ratio_lin, ids, val);
     } else {
         const uint32_t *cn = (which == 0 ? ma.candA_node : ma.candB_node) + (size_t)gi * KMAX;
         const double *cv = (which == 0 ? ma.candA_val : ma.candB_val) + (size_t)gi * KMAX;
-        for (int j = threadIdx.x; j < n; j += 64) {
+        for (int j = threadIdx.x; j < n; j += BLOCK) {
             ids[j] = cn[j];
             val[j] = cv[j];
         }
     }
     __syncthreads();
+    if (threadIdx.x >= 64) return;  // the sort + record write is a single-wave job
     const uint64_t pidx = ma.lane_pos0[gi] + (uint64_t)(mi - 1);
     if (!emit_mapping<KMAX>(ma.mpool, pidx, ids, val, n, ma.ratio_lin, true, order)) {
         if (threadIdx.x == 0) atomicOr(&ma.err[gi], SP_ERR_POOL);
@@ -366,22 +402,24 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
     const int W = mc.W, lanes = mc.lanes;
     const std::vector<int> &hl = *mc.hl, &hsw = *mc.hsw;
     const std::vector<uint64_t> &lp0 = *mc.lane_pos0;
-    const uint64_t n_pos = lp0[lanes];
     const size_t NW = (size_t)m->N * W;
 
-    // per-lane control
+    // per-lane control: last dense backward column, global position base of the lane's read
     std::vector<int> hb(lanes, 0);
+    std::vector<uint64_t> gp0(lanes + 1, 0);
     int pos_max = -1;
     for (int gi = 0; gi < lanes; gi++) {
-        if (hl[gi] == 0) {
+        const size_t slot = (size_t)g0 * W + gi;
+        if (hl[gi] == 0 || slot >= R) {
             hb[gi] = -1;
             continue;
         }
+        gp0[gi] = sink->reads->off[plan.order[slot]];
         if (hsw[gi] < hl[gi]) hb[gi] = hsw[gi] | (1 << 30);
         else hb[gi] = hl[gi] - 1;
         pos_max = std::max(pos_max, hb[gi] & ~(1 << 30));
     }
-    DevBuf &ctl = m->ws_aux[3], &pbuf = m->ws_aux[4], &mpool = m->ws_aux[5], &mmeta = m->ws_aux[6];
+    DevBuf &ctl = m->ws_aux[3], &pbuf = m->ws_aux[4];
     size_t cb = 0;
     auto carve = [&](size_t bytes) {
         cb = (cb + 255) / 256 * 256;
@@ -391,28 +429,24 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
     };
     const size_t o_bs = carve(sizeof(int) * lanes), o_ca = carve(sizeof(int) * lanes), o_cb = carve(sizeof(int) * lanes),
                  o_err = carve(sizeof(uint32_t) * lanes), o_lanes = carve(sizeof(uint32_t) * std::max<size_t>(sparse_lanes.size(), 1)),
-                 o_lp0 = carve(sizeof(uint64_t) * (lanes + 1)),
+                 o_lp0 = carve(sizeof(uint64_t) * (lanes + 1)), o_gp0 = carve(sizeof(uint64_t) * (lanes + 1)),
                  o_bn = carve(sizeof(uint32_t) * (size_t)lanes * KMAX), o_bv = carve(sizeof(double) * (size_t)lanes * KMAX);
     ctl.reserve(cb);
     char *cp = (char *)ctl.p;
     pbuf.reserve(2 * (size_t)mc.ngc * NW * sizeof(double));
-    uint64_t map_cap = n_pos * 256 + (1u << 20);
+    unsigned long long top_before = 0;
+    HIP_CHECK(hipMemcpyAsync(&top_before, sink->mp.top, sizeof(top_before), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
 
     for (int attempt = 0;; attempt++) {
-        HIP_CHECK(hipMemsetAsync(cp, 0, cb, s));
+        HIP_CHECK(hipMemsetAsync(cp, 0, o_bn, s));
         HIP_CHECK(hipMemcpyAsync(cp + o_bs, hb.data(), sizeof(int) * lanes, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(cp + o_lp0, lp0.data(), sizeof(uint64_t) * (lanes + 1), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(cp + o_gp0, gp0.data(), sizeof(uint64_t) * (lanes + 1), hipMemcpyHostToDevice, s));
         if (!sparse_lanes.empty())
             HIP_CHECK(hipMemcpyAsync(cp + o_lanes, sparse_lanes.data(), sizeof(uint32_t) * sparse_lanes.size(),
                                      hipMemcpyHostToDevice, s));
-        mpool.reserve(map_cap);
-        mmeta.reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1));
-        HIP_CHECK(hipMemsetAsync(mmeta.p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1), s));
-        RecPool mp{};
-        mp.base = mpool.as<uint8_t>();
-        mp.cap = map_cap;
-        mp.top = mmeta.as<unsigned long long>();
-        mp.off = (uint64_t *)(mmeta.as<char>() + 8);
+        const RecPool mp = sink->mp;
 
         DenseArgs a = mc.a;
         a.want_freq = 0;
@@ -439,6 +473,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             ba.fpool = mc.fpool;
             ba.mpool = mp;
             ba.lane_pos0 = (const uint64_t *)(cp + o_lp0);
+            ba.map_pos0 = (const uint64_t *)(cp + o_gp0);
             ba.lanes = (const uint32_t *)(cp + o_lanes);
             ba.ratio_lin = mc.ratio_lin;
             ba.err = (uint32_t *)(cp + o_err);
@@ -451,7 +486,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.d = a;
         ma.W = W;
         ma.mpool = mp;
-        ma.lane_pos0 = (const uint64_t *)(cp + o_lp0);
+        ma.lane_pos0 = (const uint64_t *)(cp + o_gp0);
         ma.cntA = (int *)(cp + o_ca);
         ma.cntB = (int *)(cp + o_cb);
         ma.candA_node = mc.cand_node;
@@ -466,99 +501,178 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             launch_bwd_step(W, a, pos);
             lt.end();
             launch_post_collect_w(W, ma, pos);
-            hipLaunchKernelGGL(emit_dense_map, dim3(lanes, 2), dim3(64), 0, s, ma, pos);
+            hipLaunchKernelGGL(emit_dense_map, dim3(lanes, 2), dim3(BLOCK), 0, s, ma, pos);
             st.launches[1]++;
         }
         HIP_CHECK(hipGetLastError());
         st.ms[1] += lt.total_ms();
         for (int gi = 0; gi < lanes; gi++)
-            if (hl[gi] > 0) st.cells[1] += (uint64_t)((hb[gi] & ~(1 << 30)) + 1) * m->N;
+            if (hb[gi] >= 0) st.cells[1] += (uint64_t)((hb[gi] & ~(1 << 30)) + 1) * m->N;
         std::vector<uint32_t> herr(lanes);
         HIP_CHECK(hipMemcpyAsync(herr.data(), cp + o_err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        trace("  dense backward+collect");
         bool pool_full = false;
         for (int gi = 0; gi < lanes; gi++) {
             if (herr[gi] & SP_ERR_POOL) pool_full = true;
             else if (herr[gi]) PHMM_THROW(PHMM_EINTERNAL, "mapping backward error " + std::to_string(herr[gi]));
         }
-        if (!pool_full) {
-            trace("  dense backward+collect");
-            // gather the records
-            unsigned long long used = 0;
-            HIP_CHECK(hipMemcpy(&used, mp.top, sizeof(used), hipMemcpyDeviceToHost));
-            std::vector<uint8_t> hp(used);
-            std::vector<uint64_t> hoff(n_pos);
-            if (used) HIP_CHECK(hipMemcpy(hp.data(), mp.base, used, hipMemcpyDeviceToHost));
-            if (n_pos) HIP_CHECK(hipMemcpy(hoff.data(), mp.off, sizeof(uint64_t) * n_pos, hipMemcpyDeviceToHost));
-            for (int gi = 0; gi < lanes; gi++) {
-                const size_t slot = (size_t)g0 * W + gi;
-                if (slot >= R || hl[gi] == 0) continue;
-                const uint32_t rd = plan.order[slot];
-                auto &cnt = sink->count[rd];
-                auto &nd = sink->nodes[rd];
-                auto &lg = sink->logp[rd];
-                cnt.assign(hl[gi], 0);
-                for (int i = 0; i < hl[gi]; i++) {
-                    const uint64_t o1 = hoff[lp0[gi] + i];
-                    if (!o1) continue;
-                    const uint8_t *rec = hp.data() + (o1 - 8);
-                    const uint32_t n = ((const uint32_t *)rec)[0];
-                    const uint64_t idb = (uint64_t)((n + 1) & ~1u) * 4;
-                    const uint32_t *ids = (const uint32_t *)(rec + 8);
-                    const double *lps = (const double *)(rec + 8 + idb);
-                    cnt[i] = n;
-                    nd.insert(nd.end(), ids, ids + n);
-                    lg.insert(lg.end(), lps, lps + n);
-                }
-            }
-            trace("  gather+assemble");
-            break;
-        }
+        if (!pool_full) break;
         if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "mapping pool keeps overflowing");
-        map_cap *= 2;
+        // grow the pool: keep what earlier chunks wrote, drop this chunk's partial output
+        DevBuf bigger;
+        bigger.reserve(sink->cap * 2);
+        if (top_before) HIP_CHECK(hipMemcpyAsync(bigger.p, sink->mp.base, top_before, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(sink->mp.top, &top_before, sizeof(top_before), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::swap(bigger.p, m->ws_aux[5].p);
+        std::swap(bigger.bytes, m->ws_aux[5].bytes);
+        sink->cap *= 2;
+        sink->mp.base = m->ws_aux[5].as<uint8_t>();
+        sink->mp.cap = sink->cap;
     }
+}
+
+// ---------------------------------------------------------------- final CSR on the device
+__global__ void __launch_bounds__(BLOCK) map_counts(RecPool mp, uint64_t n_pos, uint64_t *cnt) {
+    const uint64_t p = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (p > n_pos) return;
+    uint64_t c = 0;
+    if (p < n_pos) {
+        const uint64_t o1 = mp.off[p];
+        if (o1) c = ((const uint32_t *)(mp.base + (o1 - 8)))[0];
+    }
+    cnt[p] = c;
+}
+__global__ void __launch_bounds__(BLOCK) map_compact(RecPool mp, uint64_t n_pos, const uint64_t *pos_off, uint32_t *nodes,
+                                                     double *logp) {
+    const uint64_t p = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= n_pos) return;
+    const uint64_t o1 = mp.off[p];
+    if (!o1) return;
+    const uint8_t *rec = mp.base + (o1 - 8);
+    const uint32_t n = ((const uint32_t *)rec)[0];
+    const uint64_t idb = (uint64_t)((n + 1) & ~1u) * 4;
+    const uint32_t *ids = (const uint32_t *)(rec + 8);
+    const double *lps = (const double *)(rec + 8 + idb);
+    const uint64_t w = pos_off[p];
+    for (uint32_t j = 0; j < n; j++) {
+        nodes[w + j] = ids[j];
+        logp[w + j] = lps[j];
+    }
+}
+__global__ void __launch_bounds__(BLOCK) map_read_max(const uint64_t *read_off, uint64_t R, const uint64_t *pos_off,
+                                                      uint32_t *out) {
+    const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= R) return;
+    uint32_t mx = 0;
+    for (uint64_t p = read_off[r]; p < read_off[r + 1]; p++) mx = max(mx, (uint32_t)(pos_off[p + 1] - pos_off[p]));
+    out[r] = mx;
+}
+__global__ void __launch_bounds__(BLOCK) map_probs(const double *logp, uint64_t n, double *prob) {
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < n) prob[j] = exp(logp[j]);
+}
+// Mappings::to_node_freqs (hint.rs:161-171) in a fixed order: entries are sorted by node (stable
+// radix sort), every node sums its own segment sequentially.
+__global__ void __launch_bounds__(BLOCK) map_node_freq(const uint32_t *sorted_nodes, const double *sorted_prob, uint64_t n,
+                                                       uint32_t N, double *freq) {
+    const uint32_t v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= N) return;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {  // first index with node >= v
+        const uint64_t mid = (lo + hi) >> 1;
+        if (sorted_nodes[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    double s = 0.0;
+    for (uint64_t j = lo; j < n && sorted_nodes[j] == v; j++) s += sorted_prob[j];
+    freq[v] = s;
 }
 
 // PHMMModel::generate_mappings(reads, None, use_max_ratio = true)
 void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq) {
-    MappingSink sink;
-    sink.count.resize(reads->R);
-    sink.nodes.resize(reads->R);
-    sink.logp.resize(reads->R);
+    hipStream_t s = current_stream();
+    const uint64_t n_pos = reads->total;
+    MappingSink sink{};
+    sink.reads = reads;
+    sink.total_pos = n_pos;
+    sink.cap = std::max<uint64_t>(m->ws_aux[5].bytes, n_pos * 160 + (1u << 20));
+    m->ws_aux[5].reserve(sink.cap);
+    m->ws_aux[6].reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1));
+    HIP_CHECK(hipMemsetAsync(m->ws_aux[6].p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1), s));
+    sink.mp.base = m->ws_aux[5].as<uint8_t>();
+    sink.mp.cap = sink.cap;
+    sink.mp.top = m->ws_aux[6].as<unsigned long long>();
+    sink.mp.off = (uint64_t *)(m->ws_aux[6].as<char>() + 8);
+
     std::vector<double> lf(reads->R);
     double tot = 0.0;
     full_prob_reads_sparse(m, reads, lf.data(), &tot, &sink);
-    auto *mp = new phmm_mappings();
+    trace("forward+backward chunks");
+
+    std::unique_ptr<phmm_mappings> mp(new phmm_mappings());
     mp->R = reads->R;
-    mp->total_pos = reads->total;
+    mp->total_pos = n_pos;
     mp->read_off = reads->off;
-    mp->pos_off.assign(reads->total + 1, 0);
-    mp->read_max_list.assign(reads->R, 0);
     mp->read_logp = lf;
-    uint64_t w = 0;
-    for (uint64_t r = 0; r < reads->R; r++) {
-        const uint64_t len = reads->off[r + 1] - reads->off[r];
-        for (uint64_t i = 0; i < len; i++) {
-            const uint32_t c = i < sink.count[r].size() ? sink.count[r][i] : 0;
-            w += c;
-            mp->pos_off[reads->off[r] + i + 1] = w;
-            mp->read_max_list[r] = std::max(mp->read_max_list[r], c);
-        }
-        mp->nodes.insert(mp->nodes.end(), sink.nodes[r].begin(), sink.nodes[r].end());
-        mp->logp.insert(mp->logp.end(), sink.logp[r].begin(), sink.logp[r].end());
-    }
+    mp->host_valid = false;
+    mp->trusted = true;
+    // counts -> exclusive scan -> compaction, all on the device
+    DevBuf &cnt = m->ws_aux[13], &tmp = m->ws_aux[14];
+    cnt.reserve(sizeof(uint64_t) * (n_pos + 1));
+    mp->d_pos_off.reserve(sizeof(uint64_t) * (n_pos + 1));
+    const unsigned nb = (unsigned)((n_pos + 1 + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(map_counts, dim3(nb), dim3(BLOCK), 0, s, sink.mp, n_pos, cnt.as<uint64_t>());
+    size_t tb = 0;
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt.as<uint64_t>(), mp->d_pos_off.as<uint64_t>(), (int)(n_pos + 1), s));
+    tmp.reserve(tb);
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt.as<uint64_t>(), mp->d_pos_off.as<uint64_t>(), (int)(n_pos + 1), s));
+    uint64_t total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, mp->d_pos_off.as<uint64_t>() + n_pos, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    mp->total_entries = total;
+    mp->d_nodes.reserve(sizeof(uint32_t) * std::max<uint64_t>(total, 1));
+    mp->d_logp.reserve(sizeof(double) * std::max<uint64_t>(total, 1));
+    hipLaunchKernelGGL(map_compact, dim3(nb), dim3(BLOCK), 0, s, sink.mp, n_pos, mp->d_pos_off.as<uint64_t>(),
+                       mp->d_nodes.as<uint32_t>(), mp->d_logp.as<double>());
+    // longest list per read (capacity class of the hinted kernel)
+    DevBuf d_roff, d_rmax;
+    d_roff.upload(reads->off.data(), sizeof(uint64_t) * (reads->R + 1));
+    d_rmax.reserve(sizeof(uint32_t) * reads->R);
+    hipLaunchKernelGGL(map_read_max, dim3((unsigned)((reads->R + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                       d_roff.as<uint64_t>(), reads->R, mp->d_pos_off.as<uint64_t>(), d_rmax.as<uint32_t>());
+    mp->read_max_list.resize(reads->R);
+    HIP_CHECK(hipMemcpyAsync(mp->read_max_list.data(), d_rmax.p, sizeof(uint32_t) * reads->R, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    mp->on_device = true;
+    trace("device CSR");
     if (out_node_freq) {
-        // Mappings::to_node_freqs (hint.rs:161-171)
-        std::vector<double> f(m->N, 0.0);
-        for (size_t a = 0; a < mp->nodes.size(); a++) f[mp->nodes[a]] += std::exp(mp->logp[a]);
-        try {
-            put_doubles(out_node_freq, f.data(), m->N);
-        } catch (...) {
-            delete mp;
-            throw;
+        DevBuf d_prob, d_sn, d_sp, d_freq;
+        const uint64_t n = std::max<uint64_t>(total, 1);
+        d_prob.reserve(sizeof(double) * n);
+        d_sn.reserve(sizeof(uint32_t) * n);
+        d_sp.reserve(sizeof(double) * n);
+        d_freq.reserve(sizeof(double) * m->N);
+        if (total) {
+            hipLaunchKernelGGL(map_probs, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+                               mp->d_logp.as<double>(), total, d_prob.as<double>());
+            int end_bit = 1;
+            while (end_bit < 32 && (1ull << end_bit) < m->N) end_bit++;
+            size_t sb = 0;
+            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, mp->d_nodes.as<uint32_t>(), d_sn.as<uint32_t>(),
+                                                         d_prob.as<double>(), d_sp.as<double>(), (int)total, 0, end_bit, s));
+            tmp.reserve(sb);
+            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, mp->d_nodes.as<uint32_t>(), d_sn.as<uint32_t>(),
+                                                         d_prob.as<double>(), d_sp.as<double>(), (int)total, 0, end_bit, s));
         }
+        hipLaunchKernelGGL(map_node_freq, dim3((m->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_sn.as<uint32_t>(),
+                           d_sp.as<double>(), total, m->N, d_freq.as<double>());
+        HIP_CHECK(hipGetLastError());
+        copy_out(out_node_freq, d_freq.p, sizeof(double) * m->N);
+        trace("node freqs");
     }
-    *out = mp;
+    *out = mp.release();
 }
 
 }  // namespace phmm

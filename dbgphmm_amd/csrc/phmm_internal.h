@@ -158,9 +158,17 @@ struct phmm_mappings {
     std::vector<double> logp;
     std::vector<uint32_t> read_max_list;  // [R] longest node list of each read
     std::vector<double> read_logp;        // [R] ln P(read) of the forward pass that produced the mappings (may be empty)
-    mutable phmm::DevBuf d_pos_off, d_nodes;
+    mutable phmm::DevBuf d_pos_off, d_nodes, d_logp;
     mutable bool on_device = false;
+    // Mappings produced by phmm_generate_mappings stay on the device (their next consumer is the
+    // hinted forward kernel); the host vectors above are filled on first host access.
+    mutable bool host_valid = true;
+    uint64_t total_entries = 0;
+    bool trusted = false;  // node ids come from our own kernels: no range check needed
 };
+namespace phmm {
+void mappings_materialize_host(const phmm_mappings *mp);
+}
 
 namespace phmm {
 

@@ -187,7 +187,6 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
     for (uint64_t r = 0; r < R; r++) {
         const uint32_t mx = mp->read_max_list[r];
         cls[mx <= 64 ? 0 : (mx <= 128 ? 1 : 2)].push_back((uint32_t)r);
-        cells += mp->pos_off[reads->off[r + 1]] - mp->pos_off[reads->off[r]];
     }
     DevBuf &d_ids = m->ws_aux[10], &d_out = m->ws_aux[11], &d_err = m->ws_aux[12];
     d_ids.reserve(R * sizeof(uint32_t));
@@ -233,6 +232,7 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
         }
     }
     st.ms[2] += tm.stop();
+    cells = mp->total_entries;
     st.cells[2] = cells * n_cand;
 
     std::vector<double> tot(n_cand, 0.0);

@@ -77,11 +77,14 @@ inline SparseModel sparse_model_of(const phmm_model *m) {
 
 namespace phmm {
 
-// Host-side collector of the mapping lists of all reads (original read order).
+// Device-side collector of the mapping lists of all reads: one record pool for the whole call,
+// record offsets indexed by the GLOBAL read position (reads->off[read] + i), so the final CSR is
+// produced on the device (counts -> scan -> compaction) without a host pass over positions.
 struct MappingSink {
-    std::vector<std::vector<uint32_t>> count;  // [read][pos]
-    std::vector<std::vector<uint32_t>> nodes;  // [read] concatenated
-    std::vector<std::vector<double>> logp;
+    RecPool mp;
+    uint64_t cap;
+    uint64_t total_pos;
+    const phmm_reads *reads;
 };
 
 // Everything the backward/mapping pass needs to know about one chunk of read groups after
