@@ -679,10 +679,26 @@ struct Carver {
 };
 
 Plan make_plan(const phmm_model *m, const phmm_reads *reads, int forced_w) {
+    std::vector<uint32_t> all(reads->R);
+    std::iota(all.begin(), all.end(), 0u);
+    Plan p = make_plan_ids(m, reads, all);
+    if (forced_w > 0 && forced_w != p.W) {
+        // only the single-read debug path forces a width
+        p.W = forced_w;
+        p.ng_total = (int)((p.order.size() + p.W - 1) / p.W);
+        const int rows = BLOCK / p.W;
+        p.nblk = (int)((m->N + (int64_t)p.npt * rows - 1) / ((int64_t)p.npt * rows));
+        p.nblk8 = (p.nblk + 7) / 8 * 8;
+    }
+    return p;
+}
+
+// plan over a subset of the reads (ids index reads->off)
+Plan make_plan_ids(const phmm_model *m, const phmm_reads *reads, const std::vector<uint32_t> &ids) {
     Plan p;
-    const uint64_t R = reads->R;
-    p.order.resize(R);
-    std::iota(p.order.begin(), p.order.end(), 0u);
+    const uint64_t R = ids.size();
+    const int forced_w = 0;
+    p.order = ids;
     std::stable_sort(p.order.begin(), p.order.end(), [&](uint32_t x, uint32_t y) {
         return reads->off[x + 1] - reads->off[x] > reads->off[y + 1] - reads->off[y];
     });

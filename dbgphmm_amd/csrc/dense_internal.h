@@ -59,6 +59,7 @@ struct Plan {
 };
 
 Plan make_plan(const phmm_model *m, const phmm_reads *reads, int forced_w);
+Plan make_plan_ids(const phmm_model *m, const phmm_reads *reads, const std::vector<uint32_t> &ids);
 void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &tb, size_t &mb);
 void fill_model_args(DenseArgs &a, const phmm_model *m);
 void host_logib(const phmm_model *m, size_t n, std::vector<double> &out);

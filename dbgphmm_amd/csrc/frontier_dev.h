@@ -249,7 +249,7 @@ __device__ void fwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
         const double pe = M.emis[k] == x ? lp.p_match : lp.p_mismatch;
         double acc = 0.0;
         for (uint32_t a = M.par_off[k]; a < M.par_off[k + 1]; a++) {
-            const double w = M.trans[M.par_edge[a]];
+            const double w = M.par_w[a];
             if (w == 0.0) continue;
             double pm, pi, pd;
             prev_get(prev, M.par_node[a], pm, pi, pd);
@@ -287,7 +287,7 @@ __device__ void fwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
             const uint32_t k = cur.id[s];
             double acc = 0.0;
             for (uint32_t a = M.par_off[k]; a < M.par_off[k + 1]; a++) {
-                const double w = M.trans[M.par_edge[a]];
+                const double w = M.par_w[a];
                 if (w == 0.0) continue;
                 const int ps = fv_find(cur, M.par_node[a]);
                 if (ps < 0) continue;

@@ -36,6 +36,7 @@ template <int CAP> __device__ bool load_record(const RecPool &p, uint64_t pos_in
     const uint8_t *rec = p.base + (o1 - 8);
     const int *hw = (const int *)rec;
     const int n = hw[0], na = hw[1], E = hw[2];
+    if (n > CAP) return false;
     if (threadIdx.x == 0) {
         f.n = n;
         f.na = na;
@@ -99,6 +100,18 @@ __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32
     return true;
 }
 
+// Capacity classes as in the forward kernel (sparse_fwd_kernel.h): the tail of a read is walked
+// by a <64>-slot kernel (many reads per CU), the few positions next to the dense/sparse switch
+// (forward records of up to 400 entries) by the <400>-slot kernel, which also hands the column
+// over to the dense backward kernel.  Between two phases the last B column travels through a
+// per-read hand-off slot in HBM.
+static constexpr int HANDOFF_CAP = 128;
+struct BHandoff {
+    int n, E;
+    uint32_t id[HANDOFF_CAP];
+    double m[HANDOFF_CAP], i[HANDOFF_CAP], d[HANDOFF_CAP];
+};
+
 struct SparseBwdArgs {
     SparseModel M;
     DenseArgs d;
@@ -111,7 +124,13 @@ struct SparseBwdArgs {
     const uint32_t *lanes;
     double ratio_lin;
     uint32_t *err;
+    int mode;        // 0: start at the last position from b_init; 1: resume from the hand-off slot
+    int *stop;       // [lanes] in (mode 1): position to compute next; out: see below
+    BHandoff *hand;  // [lanes]
 };
+// stop[gi] on exit: s0      -> finished (column s0+1 handed to the dense kernel)
+//                   len     -> nothing done (the record of the last position does not fit the class)
+//                   other p -> positions > p are done, B.tables[p+1] is in the hand-off slot
 
 template <int CAP>
 __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs a) {
@@ -131,20 +150,52 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
     const LinParams &lp = a.M.lp;
     uint32_t err = 0;
     const bool ok = logP > -INFINITY;
-    // merged index len: F.tables[len-1] (.) b_init / P   (table.rs:414-434, backward.rs:197-211)
-    if (!load_record<CAP>(a.fpool, p0 + (uint64_t)(len - 1), fr)) err |= SP_ERR_POOL;
-    if (!err) {
-        const double w = ok ? exp((double)fr.E * SP_LN2 - logP) * lp.p_end : 0.0;
-        for (int j = lane; j < fr.n; j += 64) val[j] = w * (fr.m[j] + fr.i[j] + fr.d[j]);
-        __syncthreads();
-        if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
-            err |= SP_ERR_POOL;
+    int pos;            // next position to compute
+    int have_cols = 0;  // cols[(pos+1)&1] holds B.tables[pos+1]
+    bool stopped = false;
+    int stop_at = 0;
+    if (a.mode == 0) {
+        pos = len - 1;
+        // merged index len: F.tables[len-1] (.) b_init / P   (table.rs:414-434, backward.rs:197-211)
+        if (!load_record<CAP>(a.fpool, p0 + (uint64_t)(len - 1), fr)) {
+            stopped = true;  // does not fit this class (or missing): nothing done
+            stop_at = len;
+        } else {
+            const double w = ok ? exp((double)fr.E * SP_LN2 - logP) * lp.p_end : 0.0;
+            for (int j = lane; j < fr.n; j += 64) val[j] = w * (fr.m[j] + fr.i[j] + fr.d[j]);
+            __syncthreads();
+            if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
+                err |= SP_ERR_POOL;
+        }
+    } else {
+        pos = a.stop[gi];
+        if (pos < len - 1) {
+            // B.tables[pos+1] from the hand-off slot
+            const BHandoff &h = a.hand[gi];
+            Col<CAP> &c = cols[(pos + 1) & 1];
+            const int n = h.n;
+            hash_clear(c);
+            if (lane == 0) {
+                c.n = c.na = n;
+                c.E = h.E;
+            }
+            __syncthreads();
+            for (int j = lane; j < n; j += 64) {
+                c.id[j] = h.id[j];
+                c.m[j] = h.m[j];
+                c.i[j] = h.i[j];
+                c.d[j] = h.d[j];
+                hash_insert(c, h.id[j], j);
+            }
+            __syncthreads();
+            have_cols = 1;
+        }
     }
-    int have_cols = 0;
-    for (int pos = len - 1; pos >= s0 + 1 && !err; pos--) {
+    for (; !stopped && pos >= s0 + 1 && !err; pos--) {
         // B.tables[pos] over filled_nodes(F.tables[pos-1]) (backward.rs:122-129)
         if (!load_record<CAP>(a.fpool, p0 + (uint64_t)(pos - 1), fr)) {
-            err |= SP_ERR_POOL;
+            stopped = true;  // the forward record is larger than this class
+            stop_at = pos;
             break;
         }
         for (int j = lane; j < fr.n; j += 64) val[j] = fr.m[j] + fr.i[j] + fr.d[j];
@@ -168,31 +219,54 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
         if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
             err |= SP_ERR_POOL;
     }
-    // hand B.tables[s0+1] to the dense backward kernel: dense column (zeros elsewhere = the
-    // SparseVec default), its exponent and maximum
-    if (!err && have_cols) {
-        const Col<CAP> &c = cols[(s0 + 1) & 1];
-        const size_t NW = (size_t)a.d.N * a.W;
-        const int pc = (s0 + 1) & 1;
-        double *bm = a.d.Bm + ((size_t)g * a.d.bcols + pc) * NW;
-        double *bi = a.d.Bi + ((size_t)g * a.d.bcols + pc) * NW;
-        for (int k = lane; k < a.d.N; k += 64) {
-            bm[(size_t)k * a.W + r] = 0.0;
-            bi[(size_t)k * a.W + r] = 0.0;
+    if (stopped && !err) {
+        // park B.tables[stop_at + 1] for the next phase
+        if (have_cols && stop_at < len) {
+            const Col<CAP> &c = cols[(stop_at + 1) & 1];
+            BHandoff &h = a.hand[gi];
+            if (c.n > HANDOFF_CAP) err |= SP_ERR_CAPACITY;
+            else {
+                if (lane == 0) {
+                    h.n = c.n;
+                    h.E = c.E;
+                }
+                for (int j = lane; j < c.n; j += 64) {
+                    h.id[j] = c.id[j];
+                    h.m[j] = c.m[j];
+                    h.i[j] = c.i[j];
+                    h.d[j] = c.d[j];
+                }
+            }
         }
-        __threadfence();
-        __syncthreads();
-        double mx = 0.0;
-        for (int j = lane; j < c.n; j += 64) {
-            bm[(size_t)c.id[j] * a.W + r] = c.m[j];
-            bi[(size_t)c.id[j] * a.W + r] = c.i[j];
-            mx = fmax(mx, fmax(c.m[j], c.i[j]));
+        if (lane == 0) a.stop[gi] = stop_at;
+    } else if (!err) {
+        // hand B.tables[s0+1] to the dense backward kernel: dense column (zeros elsewhere = the
+        // SparseVec default), its exponent and maximum
+        if (have_cols) {
+            const Col<CAP> &c = cols[(s0 + 1) & 1];
+            const size_t NW = (size_t)a.d.N * a.W;
+            const int pc = (s0 + 1) & 1;
+            double *bm = a.d.Bm + ((size_t)g * a.d.bcols + pc) * NW;
+            double *bi = a.d.Bi + ((size_t)g * a.d.bcols + pc) * NW;
+            for (int k = lane; k < a.d.N; k += 64) {
+                bm[(size_t)k * a.W + r] = 0.0;
+                bi[(size_t)k * a.W + r] = 0.0;
+            }
+            __threadfence();
+            __syncthreads();
+            double mx = 0.0;
+            for (int j = lane; j < c.n; j += 64) {
+                bm[(size_t)c.id[j] * a.W + r] = c.m[j];
+                bi[(size_t)c.id[j] * a.W + r] = c.i[j];
+                mx = fmax(mx, fmax(c.m[j], c.i[j]));
+            }
+            mx = wave_max(mx);
+            if (lane == 0) {
+                a.d.cmaxB[((size_t)g * a.d.Lc + (s0 + 1)) * a.W + r] = (unsigned long long)__double_as_longlong(mx);
+                a.d.BE[((size_t)g * (a.d.Lc + 1) + (s0 + 1)) * a.W + r] = c.E;
+            }
         }
-        mx = wave_max(mx);
-        if (lane == 0) {
-            a.d.cmaxB[((size_t)g * a.d.Lc + (s0 + 1)) * a.W + r] = (unsigned long long)__double_as_longlong(mx);
-            a.d.BE[((size_t)g * (a.d.Lc + 1) + (s0 + 1)) * a.W + r] = c.E;
-        }
+        if (lane == 0) a.stop[gi] = s0;
     }
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
     if (lane == 0) a.err[gi] = err;
@@ -430,7 +504,9 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
     const size_t o_bs = carve(sizeof(int) * lanes), o_ca = carve(sizeof(int) * lanes), o_cb = carve(sizeof(int) * lanes),
                  o_err = carve(sizeof(uint32_t) * lanes), o_lanes = carve(sizeof(uint32_t) * std::max<size_t>(sparse_lanes.size(), 1)),
                  o_lp0 = carve(sizeof(uint64_t) * (lanes + 1)), o_gp0 = carve(sizeof(uint64_t) * (lanes + 1)),
-                 o_bn = carve(sizeof(uint32_t) * (size_t)lanes * KMAX), o_bv = carve(sizeof(double) * (size_t)lanes * KMAX);
+                 o_stop = carve(sizeof(int) * lanes),
+                 o_bn = carve(sizeof(uint32_t) * (size_t)lanes * KMAX), o_bv = carve(sizeof(double) * (size_t)lanes * KMAX),
+                 o_hand = carve(sizeof(BHandoff) * (size_t)lanes);
     ctl.reserve(cb);
     char *cp = (char *)ctl.p;
     pbuf.reserve(2 * (size_t)mc.ngc * NW * sizeof(double));
@@ -477,9 +553,57 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             ba.lanes = (const uint32_t *)(cp + o_lanes);
             ba.ratio_lin = mc.ratio_lin;
             ba.err = (uint32_t *)(cp + o_err);
-            hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)sparse_lanes.size()), dim3(64), 0, s, ba);
-            HIP_CHECK(hipGetLastError());
-            st.launches[3]++;
+            ba.stop = (int *)(cp + o_stop);
+            ba.hand = (BHandoff *)(cp + o_hand);
+            // phase 1 <64>: the tail of every read; phase 2 <400>: the positions next to the switch (and
+            // the hand-over to the dense kernel); repeated while a read still has positions left
+            std::vector<uint32_t> todo = sparse_lanes;
+            std::vector<int> hstop(lanes);
+            std::vector<uint32_t> herr2(lanes);
+            for (int round = 0; round < 64 && !todo.empty(); round++) {
+                const bool small = (round & 1) == 0;
+                HIP_CHECK(hipMemcpyAsync(cp + o_lanes, todo.data(), sizeof(uint32_t) * todo.size(), hipMemcpyHostToDevice, s));
+                ba.mode = round == 0 ? 0 : 1;
+                if (small)
+                    hipLaunchKernelGGL((sparse_backward_kernel<64>), dim3((unsigned)todo.size()), dim3(64), 0, s, ba);
+                else
+                    hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)todo.size()), dim3(64), 0, s, ba);
+                HIP_CHECK(hipGetLastError());
+                st.launches[3]++;
+                HIP_CHECK(hipMemcpyAsync(hstop.data(), ba.stop, sizeof(int) * lanes, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipMemcpyAsync(herr2.data(), ba.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                std::vector<uint32_t> next;
+                bool any_err = false;
+                for (uint32_t gi : todo) {
+                    if (herr2[gi]) any_err = true;
+                    else if (hstop[gi] != hsw[gi]) next.push_back(gi);
+                }
+                if (any_err) break;  // reported below (pool growth / internal error)
+                if (round == 0) {
+                    // a read whose LAST record did not fit <64> has done nothing: it restarts in mode 0
+                    bool restart = false;
+                    for (uint32_t gi : next)
+                        if (hstop[gi] == hl[gi]) restart = true;
+                    if (restart) {
+                        std::vector<uint32_t> rs, keep;
+                        for (uint32_t gi : next) (hstop[gi] == hl[gi] ? rs : keep).push_back(gi);
+                        HIP_CHECK(hipMemcpyAsync(cp + o_lanes, rs.data(), sizeof(uint32_t) * rs.size(), hipMemcpyHostToDevice, s));
+                        ba.mode = 0;
+                        hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)rs.size()), dim3(64), 0, s, ba);
+                        HIP_CHECK(hipGetLastError());
+                        HIP_CHECK(hipStreamSynchronize(s));
+                        next.swap(keep);
+                    }
+                }
+                todo.swap(next);
+            }
+            if (!todo.empty()) {
+                bool perr = false;
+                HIP_CHECK(hipMemcpy(herr2.data(), ba.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost));
+                for (uint32_t gi : sparse_lanes) perr |= herr2[gi] != 0;
+                if (!perr) PHMM_THROW(PHMM_EINTERNAL, "sparse backward did not finish");
+            }
         }
         trace("  sparse backward");
         DenseMapArgs ma{};

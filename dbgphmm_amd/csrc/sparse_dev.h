@@ -110,6 +110,7 @@ struct SparseModel {
     const uint32_t *par_off, *par_node, *par_edge;
     const uint32_t *chi_off, *chi_node, *chi_edge;
     const double *trans;  // [E] by edge id (per candidate: offset applied by the caller)
+    const double *par_w, *chi_w;  // [E] linear trans prob aligned with par_node / chi_node (the model's own)
     LinParams lp;
     const double *logib;  // forward InsBegin chain (log), [>= max read length]
 };
@@ -255,7 +256,7 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
         const uint32_t v = cur.id[j];
         double a1 = 0.0;
         for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
-            const double w = M.trans[M.chi_edge[a]];
+            const double w = M.chi_w[a];
             if (w == 0.0) continue;
             const uint32_t u = M.chi_node[a];
             double mu = 0.0;
@@ -287,7 +288,7 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
             const uint32_t v = cur.id[j];
             double s = 0.0;
             for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
-                const double w = M.trans[M.chi_edge[a]];
+                const double w = M.chi_w[a];
                 if (w == 0.0) continue;
                 const int cs = hash_find(cur, M.chi_node[a]);
                 if (cs >= 0) s += w * src[cs];
@@ -306,7 +307,7 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
         const uint32_t v = cur.id[j];
         double td = 0.0;
         for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
-            const double w = M.trans[M.chi_edge[a]];
+            const double w = M.chi_w[a];
             if (w == 0.0) continue;
             const int cs = hash_find(cur, M.chi_node[a]);
             if (cs >= 0) td += w * cur.d[cs];

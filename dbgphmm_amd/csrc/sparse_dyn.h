@@ -66,6 +66,8 @@ inline SparseModel sparse_model_of(const phmm_model *m) {
     s.chi_node = d.chi_node.as<uint32_t>();
     s.chi_edge = d.chi_edge.as<uint32_t>();
     s.trans = d.trans_lin.as<double>();
+    s.par_w = d.par_w.as<double>();
+    s.chi_w = d.chi_w.as<double>();
     s.lp = m->lin;
     s.logib = d.logib.as<double>();
     return s;

@@ -13,11 +13,13 @@
 //   * each read then continues on its own wave64 with the frontier in LDS (frontier_dev.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "dense_internal.h"
 #include "frontier_dev.h"
 #include "sparse_dyn.h"
+#include "sparse_fwd_kernel.h"
 
 namespace phmm {
 
@@ -212,96 +214,6 @@ __global__ void __launch_bounds__(BLOCK) select_top400(const Top400Args a) {
     if (threadIdx.x == 0) a.cand_n[gi] = cnt < K ? cnt : K;
 }
 
-struct SparseFwdArgs {
-    SparseModel M;
-    DenseArgs d;  // dense warm-up tables of the chunk
-    int W;
-    const int *sw;
-    const uint32_t *cand_node;
-    const double *cand_tot;
-    const int *cand_n;
-    const uint32_t *lanes;  // [n] flattened (g*W + r) of the reads handled by this launch
-    const uint8_t *bases;   // chunk-transposed full-length bases [ng][Lb][W]
-    int Lb;
-    double ratio_lin;
-    double *out_logp;  // [ng*W]
-    uint32_t *err;     // [ng*W]
-    // optional table storage (generate_mappings): one record per sparse position
-    RecPool pool;
-    const uint64_t *lane_pos0;  // [ng*W] first position index of each lane
-};
-
-template <int CAP>
-__global__ void __launch_bounds__(64) sparse_forward_kernel(const SparseFwdArgs a) {
-    __shared__ FVec<CAP> cols[2];
-    __shared__ FScratch<CAP> sc;
-    const int lane = threadIdx.x;
-    const uint32_t gi = a.lanes[blockIdx.x];
-    const int g = (int)(gi / a.W), r = (int)(gi % a.W);
-    const int len = a.d.len[gi];
-    const int s0 = a.sw[gi];
-    const size_t NW = (size_t)a.d.N * a.W;
-    if (lane == 0) sc.dropped = 0;
-    // ---- first sparse column: top list = candidates of dense column s0-1 sorted by
-    // (total desc, node asc) = the reference's stable sort over the dense nodevec
-    const int nc = a.cand_n[gi];
-    uint32_t err = 0;
-    if (nc > CAP) err |= SP_ERR_CAPACITY;
-    FVec<CAP> &c0 = cols[s0 & 1];
-    fv_clear(c0);
-    __syncthreads();
-    if (!err) {
-        const uint32_t *cn = a.cand_node + (size_t)gi * PHMM_MAX_ACTIVE_NODES;
-        const double *ct = a.cand_tot + (size_t)gi * PHMM_MAX_ACTIVE_NODES;
-        for (int j = lane; j < nc; j += 64) {
-            const double v = ct[j];
-            const uint32_t id = cn[j];
-            int rank = 0;
-            for (int q = 0; q < nc; q++) {
-                const double u = ct[q];
-                rank += (u > v) || (u == v && cn[q] < id);
-            }
-            c0.id[rank] = id;
-            c0.m[rank] = c0.i[rank] = c0.d[rank] = 0.0;
-        }
-        __syncthreads();
-        for (int j = lane; j < nc; j += 64) {
-            const uint32_t cell = fv_cell(c0, c0.id[j]);
-            c0.hslot[cell] = (uint16_t)j;
-        }
-        if (lane == 0) c0.n = nc;
-        __syncthreads();
-        PrevRef<CAP> pr{};
-        pr.vec = nullptr;
-        pr.gm = a.d.Fm + ((size_t)g * a.d.Lc + (s0 - 1)) * NW;
-        pr.gi = a.d.Fi + ((size_t)g * a.d.Lc + (s0 - 1)) * NW;
-        pr.gd = a.d.Fd + ((size_t)g * a.d.Lc + (s0 - 1)) * NW;
-        pr.W = a.W;
-        pr.lane = r;
-        pr.sc = 1.0;
-        pr.E = a.d.FE[((size_t)g * (a.d.Lc + 1) + (s0 - 1)) * a.W + r];
-        pr.is_init = false;
-        fwd_adaptive_step<CAP>(a.M, pr, c0, sc, a.bases[((size_t)g * a.Lb + s0) * a.W + r], s0);
-        if (a.pool.base && !store_record<CAP>(a.pool, a.lane_pos0[gi] + s0, c0)) err |= SP_ERR_POOL;
-        for (int pos = s0 + 1; pos < len; pos++) {
-            FVec<CAP> &prev = cols[(pos + 1) & 1];
-            FVec<CAP> &cur = cols[pos & 1];
-            select_top<CAP>(prev, cur, sc, true, a.ratio_lin, 0);
-            PrevRef<CAP> p2{};
-            p2.vec = &prev;
-            p2.E = prev.E;
-            p2.is_init = false;
-            fwd_adaptive_step<CAP>(a.M, p2, cur, sc, a.bases[((size_t)g * a.Lb + pos) * a.W + r], pos);
-            if (a.pool.base && !store_record<CAP>(a.pool, a.lane_pos0[gi] + pos, cur)) err |= SP_ERR_POOL;
-        }
-    }
-    const double lp = err ? NAN : fv_log_end(a.M, cols[(len - 1) & 1]);
-    if (lane == 0) {
-        a.out_logp[gi] = lp;
-        a.err[gi] = err | (sc.dropped && CAP < PHMM_MAX_ACTIVE_NODES ? SP_ERR_CAPACITY : 0u);
-    }
-}
-
 namespace {
 
 template <int W> void launch_col_count(const WarmArgs &wa, int col) {
@@ -333,12 +245,19 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         PHMM_THROW(PHMM_EINVAL, "sparse path supports node degree <= 8 (MultiDbg MAX_DEGREE is 5)");
     ensure_logib(m, reads->max_len + 1);
     const phmm_params &prm = m->params;
-    Plan plan = make_plan(m, reads, 0);
+    std::vector<double> lf(R, 0.0);
+    DevBuf &warm = m->ws_aux[0];  // per-chunk warm-up control arrays
+    DevBuf &fpool = m->ws_aux[1], &fpool_meta = m->ws_aux[2];  // forward table records (generate_mappings)
+
+    // Dense columns kept per read group: the switch normally happens after ~log4(N/200) + a few
+    // columns, far before n_warmup.  The first pass keeps 20; the few reads that are still dense
+    // there (e.g. a read that starts with errors) are deferred to a second, small pass that keeps
+    // all n_warmup+2 columns.
+    auto run_plan = [&](const Plan &plan, const int64_t lc_cap, std::vector<uint32_t> *deferred) {
     const int W = plan.W;
     const size_t NW = (size_t)m->N * W;
     const uint64_t limit = table_budget(m->ws_tables.bytes);
-    std::vector<double> lf(R, 0.0);
-
+    const uint64_t R = plan.order.size();  // reads of THIS plan (slots beyond it are padding)
     DenseArgs base{};
     fill_model_args(base, m);
     base.nblk = plan.nblk;
@@ -346,16 +265,13 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     base.npt = plan.npt;
     base.eall = 0;
     base.want_freq = 0;
-
-    DevBuf &warm = m->ws_aux[0];  // per-chunk warm-up control arrays
-    DevBuf &fpool = m->ws_aux[1], &fpool_meta = m->ws_aux[2];  // forward table records (generate_mappings)
     int g0 = 0;
     while (g0 < plan.ng_total) {
         const uint32_t r0 = plan.order[(size_t)g0 * W];
         const int Lfull = (int)(reads->off[r0 + 1] - reads->off[r0]);
         // dense columns kept: at most n_warmup (+1 so that the launch that writes d of the last
         // dense column has somewhere to put its speculative next column)
-        const int Lc = (int)std::min<int64_t>(Lfull, prm.n_warmup + 2);
+        const int Lc = (int)std::min<int64_t>(Lfull, std::min<int64_t>(prm.n_warmup + 2, lc_cap));
         const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8;
         int ngc = (int)std::min<uint64_t>(plan.ng_total - g0, std::max<uint64_t>(1, limit / std::max<size_t>(per_group, 1)));
         DenseArgs a = base;
@@ -459,6 +375,19 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         HIP_CHECK(hipMemcpyAsync(hcn.data(), wa.cand_n, sizeof(int) * lanes, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(tlf.data(), a.logPf, sizeof(double) * lanes, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        {
+            // a read that ran out of kept dense columns before its switch: redo the chunk with all of them
+            for (int gi = 0; gi < lanes; gi++)
+                if (hl[gi] > Lc && hsw[gi] >= Lc) {
+                    if (!deferred) PHMM_THROW(PHMM_EINTERNAL, "warm-up ran past n_warmup");
+                    const size_t slot = (size_t)g0 * W + gi;
+                    deferred->push_back(plan.order[slot]);
+                    if (std::getenv("PHMM_TRACE"))
+                        std::fprintf(stderr, "      read %u (len %d) still dense at column %d: deferred\n", plan.order[slot],
+                                     hl[gi], Lc);
+                    hl[gi] = 0;  // not part of this chunk any more
+                }
+        }
         std::vector<uint32_t> sparse_lanes, need400;
         for (int gi = 0; gi < lanes; gi++) {
             if (hl[gi] == 0) continue;
@@ -529,39 +458,61 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             std::vector<uint64_t> lane_pos0(lanes + 1, 0);
             for (int gi = 0; gi < lanes; gi++) lane_pos0[gi + 1] = lane_pos0[gi] + (uint64_t)hl[gi];
             const uint64_t n_pos = lane_pos0[lanes];
-            uint64_t pool_cap = 0;
-            if (sink) {
-                uint64_t sparse_pos = 0;
-                for (uint32_t gi : sparse_lanes) sparse_pos += (uint64_t)(hl[gi] - hsw[gi]);
-                pool_cap = sparse_pos * 1024 + (uint64_t)sparse_lanes.size() * 65536 + (1u << 20);
-            }
+            uint64_t sparse_pos = 0;
+            for (uint32_t gi : sparse_lanes) sparse_pos += (uint64_t)(hl[gi] - hsw[gi]);
+            uint64_t pool_cap = std::max<uint64_t>(fpool.bytes, sparse_pos * 1024 + (uint64_t)sparse_lanes.size() * 65536 + (1u << 20));
+            const size_t o_stop = o_cnt;  // the per-lane count array of the warm-up is free again
+            fa.stop = (int *)(wp + o_stop);
             for (int attempt = 0;; attempt++) {
-                if (sink) {
-                    fpool.reserve(pool_cap);
-                    fpool_meta.reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1) * 2);
-                    HIP_CHECK(hipMemsetAsync(fpool_meta.p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1) * 2, s));
-                    fa.pool.base = fpool.as<uint8_t>();
-                    fa.pool.cap = pool_cap;
-                    fa.pool.top = fpool_meta.as<unsigned long long>();
-                    fa.pool.off = (uint64_t *)(fpool_meta.as<char>() + 8);
-                    uint64_t *d_lp0 = fa.pool.off + n_pos;
-                    HIP_CHECK(hipMemcpyAsync(d_lp0, lane_pos0.data(), sizeof(uint64_t) * lanes, hipMemcpyHostToDevice, s));
-                    fa.lane_pos0 = d_lp0;
-                }
-                hipLaunchKernelGGL((sparse_forward_kernel<PHMM_MAX_ACTIVE_NODES>), dim3((unsigned)sparse_lanes.size()),
-                                   dim3(64), 0, s, fa);
-                HIP_CHECK(hipGetLastError());
-                st.launches[2]++;
+                fpool.reserve(pool_cap);
+                fpool_meta.reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1) * 2);
+                HIP_CHECK(hipMemsetAsync(fpool_meta.p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1) * 2, s));
+                fa.pool.base = fpool.as<uint8_t>();
+                fa.pool.cap = pool_cap;
+                fa.pool.top = fpool_meta.as<unsigned long long>();
+                fa.pool.off = (uint64_t *)(fpool_meta.as<char>() + 8);
+                uint64_t *d_lp0 = fa.pool.off + n_pos;
+                HIP_CHECK(hipMemcpyAsync(d_lp0, lane_pos0.data(), sizeof(uint64_t) * lanes, hipMemcpyHostToDevice, s));
+                fa.lane_pos0 = d_lp0;
+                // phase A <400>: the first positions after the switch (frontier up to 400 nodes);
+                // phase B <64>: the rest; phase C <400>: whatever phase B could not hold
+                std::vector<uint32_t> todo = sparse_lanes;
                 std::vector<uint32_t> herr(lanes);
-                HIP_CHECK(hipMemcpyAsync(slp.data(), fa.out_logp, sizeof(double) * lanes, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipMemcpyAsync(herr.data(), fa.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipStreamSynchronize(s));
+                std::vector<int> hstop(lanes);
                 bool pool_full = false;
-                for (uint32_t gi : sparse_lanes) {
-                    if (herr[gi] & SP_ERR_POOL) pool_full = true;
-                    else if (herr[gi])
-                        PHMM_THROW(PHMM_ECAPACITY, "sparse forward: frontier error " + std::to_string(herr[gi]));
+                for (int round = 0; round < 64 && !todo.empty() && !pool_full; round++) {
+                    // round 0: A <400> from the dense column; then B <64> to the end, and for the reads
+                    // it could not hold a short C <400> burst followed by B again
+                    const int phase = round == 0 ? 0 : ((round & 1) ? 1 : 2);
+                    HIP_CHECK(hipMemcpyAsync(wp + o_lanes, todo.data(), todo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                    fa.mode = phase == 0 ? 0 : 1;
+                    fa.max_steps = phase == 0 ? 6 : (phase == 2 ? 8 : 0);
+                    if (phase == 1)
+                        hipLaunchKernelGGL((sparse_forward_kernel<128>), dim3((unsigned)todo.size()), dim3(64), 0, s, fa);
+                    else
+                        hipLaunchKernelGGL((sparse_forward_kernel<PHMM_MAX_ACTIVE_NODES>), dim3((unsigned)todo.size()), dim3(64),
+                                           0, s, fa);
+                    HIP_CHECK(hipGetLastError());
+                    st.launches[2]++;
+                    HIP_CHECK(hipMemcpyAsync(herr.data(), fa.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
+                    HIP_CHECK(hipMemcpyAsync(hstop.data(), fa.stop, sizeof(int) * lanes, hipMemcpyDeviceToHost, s));
+                    HIP_CHECK(hipStreamSynchronize(s));
+                    std::vector<uint32_t> next;
+                    for (uint32_t gi : todo) {
+                        if (herr[gi] & SP_ERR_POOL) pool_full = true;
+                        else if ((herr[gi] & SP_ERR_CAPACITY) && phase != 1)
+                            PHMM_THROW(PHMM_ECAPACITY, "sparse forward: frontier does not fit 400 slots");
+                        else if (herr[gi] & ~SP_ERR_CAPACITY)
+                            PHMM_THROW(PHMM_EINTERNAL, "sparse forward error " + std::to_string(herr[gi]));
+                        if (hstop[gi] < hl[gi]) next.push_back(gi);
+                    }
+                    todo.swap(next);
+                    trace(phase == 0 ? "   phase A <400>" : (phase == 1 ? "   phase B <64>" : "   phase C <400>"));
+                    if (std::getenv("PHMM_TRACE")) std::fprintf(stderr, "      remaining lanes %zu\n", todo.size());
                 }
+                if (!pool_full && !todo.empty()) PHMM_THROW(PHMM_EINTERNAL, "sparse forward did not finish");
+                HIP_CHECK(hipMemcpyAsync(slp.data(), fa.out_logp, sizeof(double) * lanes, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
                 if (!pool_full) break;
                 if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "forward table pool keeps overflowing");
                 pool_cap *= 2;
@@ -623,6 +574,17 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             lf[rd] = hsw[gi] < hl[gi] ? slp[gi] : tlf[gi];
         }
         g0 += ngc;
+    }
+    };  // run_plan
+
+    std::vector<uint32_t> deferred;
+    {
+        Plan plan = make_plan(m, reads, 0);
+        run_plan(plan, 20, &deferred);
+    }
+    if (!deferred.empty()) {
+        Plan plan2 = make_plan_ids(m, reads, deferred);
+        run_plan(plan2, prm.n_warmup + 2, nullptr);
     }
     double tot = 0.0;
     for (uint64_t r = 0; r < R; r++) tot += lf[r];
