@@ -26,11 +26,18 @@ template <int CAP> struct HashSize {
     static constexpr int N = 1 << LOG2;
 };
 
+// A Col never holds more than CAP keys (no speculative inserts): half load is enough, and the
+// smaller table keeps the <64> kernels at 15-16 waves per CU.
+template <int CAP> struct ColHashSize {
+    static constexpr int LOG2 = CAP <= 64 ? 7 : (CAP <= 128 ? 8 : 10);
+    static constexpr int N = 1 << LOG2;
+};
+
 template <int CAP> struct Col {
     double m[CAP], i[CAP], d[CAP];
     uint32_t id[CAP];
-    uint32_t hkey[HashSize<CAP>::N];
-    uint16_t hslot[HashSize<CAP>::N];
+    uint32_t hkey[ColHashSize<CAP>::N];
+    uint16_t hslot[ColHashSize<CAP>::N];
     int n;   // stored entries (the reference's nodevec elements)
     int na;  // entries that carry m/i (the active list handed to f_step / b_step)
     int E;   // column exponent: true value = stored * 2^E
@@ -39,12 +46,15 @@ template <int CAP> struct Col {
 template <int CAP> __device__ __forceinline__ uint32_t hash_of(uint32_t id) {
     return (id * 2654435761u) >> (32 - HashSize<CAP>::LOG2);
 }
+template <int CAP> __device__ __forceinline__ uint32_t col_hash_of(uint32_t id) {
+    return (id * 2654435761u) >> (32 - ColHashSize<CAP>::LOG2);
+}
 template <int CAP> __device__ __forceinline__ void hash_clear(Col<CAP> &c) {
-    for (int h = threadIdx.x; h < HashSize<CAP>::N; h += 64) c.hkey[h] = H_EMPTY;
+    for (int h = threadIdx.x; h < ColHashSize<CAP>::N; h += 64) c.hkey[h] = H_EMPTY;
 }
 // returns false when the id is already present (slot is left unchanged)
 template <int CAP> __device__ __forceinline__ bool hash_insert(Col<CAP> &c, uint32_t id, int slot) {
-    uint32_t h = hash_of<CAP>(id);
+    uint32_t h = col_hash_of<CAP>(id);
     for (;;) {
         const uint32_t old = atomicCAS(&c.hkey[h], H_EMPTY, id);
         if (old == H_EMPTY) {
@@ -52,16 +62,16 @@ template <int CAP> __device__ __forceinline__ bool hash_insert(Col<CAP> &c, uint
             return true;
         }
         if (old == id) return false;
-        h = (h + 1) & (HashSize<CAP>::N - 1);
+        h = (h + 1) & (ColHashSize<CAP>::N - 1);
     }
 }
 template <int CAP> __device__ __forceinline__ int hash_find(const Col<CAP> &c, uint32_t id) {
-    uint32_t h = hash_of<CAP>(id);
+    uint32_t h = col_hash_of<CAP>(id);
     for (;;) {
         const uint32_t k = c.hkey[h];
         if (k == id) return (int)c.hslot[h];
         if (k == H_EMPTY) return -1;
-        h = (h + 1) & (HashSize<CAP>::N - 1);
+        h = (h + 1) & (ColHashSize<CAP>::N - 1);
     }
 }
 
@@ -237,6 +247,14 @@ __device__ uint32_t fwd_list_step(const SparseModel &M, const Col<CAP> &prev, Co
 template <int CAP>
 __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool prev_is_init, Col<CAP> &cur,
                               const uint32_t *list, int n, uint8_t x, double *dA, double *dB) {
+    // in-list child links cached in LDS by the bd0 pass (small classes only): the n_max_gaps Del
+    // sweeps and the bm/bi pass then need no global (CSR) access at all
+    constexpr bool LINKS = CAP <= 128;
+    constexpr int LPN = 2;
+    __shared__ int16_t lk_slot[LINKS ? CAP * LPN : 1];
+    __shared__ double lk_w[LINKS ? CAP * LPN : 1];
+    __shared__ int lk_overflow;
+    if (LINKS && threadIdx.x == 0) lk_overflow = 0;
     const LinParams &lp = M.lp;
     hash_clear(cur);
     if (threadIdx.x == 0) {
@@ -255,6 +273,7 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
     for (int j = threadIdx.x; j < n; j += 64) {
         const uint32_t v = cur.id[j];
         double a1 = 0.0;
+        int nl = 0;
         for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
             const double w = M.chi_w[a];
             if (w == 0.0) continue;
@@ -266,7 +285,19 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
                 if (ps >= 0) mu = prev.m[ps];
             }
             a1 += w * (M.emis[u] == x ? lp.p_match : lp.p_mismatch) * mu;
+            if (LINKS) {
+                const int cs = hash_find(cur, u);
+                if (cs >= 0) {
+                    if (nl < LPN) {
+                        lk_slot[j * LPN + nl] = (int16_t)cs;
+                        lk_w[j * LPN + nl] = w;
+                        nl++;
+                    } else lk_overflow = 1;
+                }
+            }
         }
+        if (LINKS)
+            for (int q = nl; q < LPN; q++) lk_slot[j * LPN + q] = -1;
         double iv = 0.0;
         if (prev_is_init) iv = pend;
         else {
@@ -287,11 +318,19 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
         for (int j = threadIdx.x; j < n; j += 64) {
             const uint32_t v = cur.id[j];
             double s = 0.0;
-            for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
-                const double w = M.chi_w[a];
-                if (w == 0.0) continue;
-                const int cs = hash_find(cur, M.chi_node[a]);
-                if (cs >= 0) s += w * src[cs];
+            if (LINKS && !lk_overflow) {
+#pragma unroll
+                for (int q = 0; q < LPN; q++) {
+                    const int cs = lk_slot[j * LPN + q];
+                    if (cs >= 0) s += lk_w[j * LPN + q] * src[cs];
+                }
+            } else {
+                for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
+                    const double w = M.chi_w[a];
+                    if (w == 0.0) continue;
+                    const int cs = hash_find(cur, M.chi_node[a]);
+                    if (cs >= 0) s += w * src[cs];
+                }
             }
             s *= lp.p_DD;
             dst[j] = s;
@@ -306,11 +345,19 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
     for (int j = threadIdx.x; j < n; j += 64) {
         const uint32_t v = cur.id[j];
         double td = 0.0;
-        for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
-            const double w = M.chi_w[a];
-            if (w == 0.0) continue;
-            const int cs = hash_find(cur, M.chi_node[a]);
-            if (cs >= 0) td += w * cur.d[cs];
+        if (LINKS && !lk_overflow) {
+#pragma unroll
+            for (int q = 0; q < LPN; q++) {
+                const int cs = lk_slot[j * LPN + q];
+                if (cs >= 0) td += lk_w[j * LPN + q] * cur.d[cs];
+            }
+        } else {
+            for (uint32_t a = M.chi_off[v]; a < M.chi_off[v + 1]; a++) {
+                const double w = M.chi_w[a];
+                if (w == 0.0) continue;
+                const int cs = hash_find(cur, M.chi_node[a]);
+                if (cs >= 0) td += w * cur.d[cs];
+            }
         }
         dA[j] = td;
     }

@@ -487,7 +487,10 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                     HIP_CHECK(hipMemcpyAsync(wp + o_lanes, todo.data(), todo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
                     fa.mode = phase == 0 ? 0 : 1;
                     fa.max_steps = phase == 0 ? 6 : (phase == 2 ? 8 : 0);
-                    if (phase == 1)
+                    // B class: 128 slots while every read still gets a wave slot (8 waves/CU), else 64 (16/CU)
+                    if (phase == 1 && todo.size() > 2048)
+                        hipLaunchKernelGGL((sparse_forward_kernel<64>), dim3((unsigned)todo.size()), dim3(64), 0, s, fa);
+                    else if (phase == 1)
                         hipLaunchKernelGGL((sparse_forward_kernel<128>), dim3((unsigned)todo.size()), dim3(64), 0, s, fa);
                     else
                         hipLaunchKernelGGL((sparse_forward_kernel<PHMM_MAX_ACTIVE_NODES>), dim3((unsigned)todo.size()), dim3(64),
