@@ -86,7 +86,7 @@ struct OpAdd {
 // Launch `pos` (0..Lc): column pos of m,i for lanes with pos < len; d of column pos-1
 // for lanes with 1 <= pos <= len; the end sum of the last column for lanes with pos == len.
 template <int W>
-__global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int pos) {
+__global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const int pos) {
     __shared__ double lds[(BLOCK / 64) * 64];
     const int g = blockIdx.y;
     const int lb = xcd_block(blockIdx.x, a.nblk8);
@@ -136,28 +136,35 @@ __global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int p
         for (int h = 0; h < H; h++) wg[h] = 0.0;
         const double c = lp.p_ID * ibs;  // p_MD*mb + p_ID*ib with mb = 0 (fmb)
         const double cb = lp.p_IM * ibs;
-        // software pipeline: the own loads of node k+1 are issued before node k is computed
+        // software pipeline: a ring of PF own-value loads stays in flight -- node k+PF is requested
+        // before node k is computed (npt is a multiple of PF; the ring is indexed statically)
+        constexpr int PF = 2;
         const bool ld = have_prev && pos >= 1;
-        double nx_m = 0.0, nx_i = 0.0;
-        {
-            int k0 = kbase;
+        double rm[PF], ri[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            int k0 = kbase + u;
             if (W == 64) k0 = __builtin_amdgcn_readfirstlane(k0);
+            rm[u] = ri[u] = 0.0;
             if (ld && k0 < a.N) {
-                nx_m = pm[(size_t)k0 * W + r];
-                nx_i = pi[(size_t)k0 * W + r];
+                rm[u] = pm[(size_t)k0 * W + r];
+                ri[u] = pi[(size_t)k0 * W + r];
             }
         }
-        for (int j = 0; j < a.npt; j++) {
+        for (int j0 = 0; j0 < a.npt; j0 += PF) {
+#pragma unroll
+          for (int u = 0; u < PF; u++) {
+            const int j = j0 + u;
             int k = kbase + j;
             if (W == 64) k = __builtin_amdgcn_readfirstlane(k);
-            if (k >= a.N) break;
+            if (k >= a.N) continue;
             if (!(newcol || have_prev)) continue;
             const NodeRec nr = a.nodes[k];
             const size_t ik = (size_t)k * W + r;
-            const double cur_m = nx_m, cur_i = nx_i;
-            if (ld && j + 1 < a.npt && k + 1 < a.N) {
-                nx_m = pm[ik + W];
-                nx_i = pi[ik + W];
+            const double cur_m = rm[u], cur_i = ri[u];
+            if (ld && j + PF < a.npt && k + PF < a.N) {
+                rm[u] = pm[ik + (size_t)PF * W];
+                ri[u] = pi[ik + (size_t)PF * W];
             }
             double mnew, inew = 0.0;
             const double pe = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
@@ -220,6 +227,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_step(const DenseArgs a, const int p
                 ci_[ik] = inew;
                 vmax = fmax(vmax, fmax(mnew, inew));
             }
+          }
         }
     }
     // column maximum -> next launch's rescale.  The InsBegin value joins the maximum so
@@ -313,7 +321,7 @@ __device__ __forceinline__ void bwd_chain(const DenseArgs &a, int g, int p, doub
 // posterior accumulation  S[pos] = F.tables[pos-1] (.) B.tables[pos] / P  (and the
 // j = L term F.tables[L-1] (.) B.init / P when pos == len-1).
 template <int W>
-__global__ void __launch_bounds__(BLOCK) bwd_step(const DenseArgs a, const int pos) {
+__global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const int pos) {
     __shared__ double lds[(BLOCK / 64) * 64];
     const int g = blockIdx.y;
     const int lb = xcd_block(blockIdx.x, a.nblk8);
