@@ -421,9 +421,11 @@ int phmm_generate_mappings(phmm_model *m, const phmm_reads *reads, const phmm_ma
         if (!m || !reads || !out) PHMM_THROW(PHMM_EINVAL, "NULL argument");
         *out = nullptr;
         if (reads->R == 0) PHMM_THROW(PHMM_EINVAL, "no reads");
-        if (mp)
-            PHMM_THROW(PHMM_EINVAL, "generate_mappings from existing mappings (run_with_mapping, freq.rs:72-76) is not "
-                                    "built on the GPU path yet; `infer` always passes None (multi_dbg/posterior.rs:735)");
+        if (mp) {
+            check_mapping_nodes(m, mp, reads);
+            generate_mappings_hinted(m, reads, mp, use_max_ratio, out, out_node_freq);
+            return;
+        }
         if (!use_max_ratio)
             PHMM_THROW(PHMM_EINVAL, "use_max_ratio = false (fixed top-k frontier) is not built on the GPU path yet; "
                                     "MultiDbg::generate_mappings always passes true (multi_dbg/posterior.rs:619)");

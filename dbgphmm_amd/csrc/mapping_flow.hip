@@ -60,7 +60,7 @@ template <int CAP> __device__ bool load_record(const RecPool &p, uint64_t pos_in
 // write [n][pad] ids logp.  Returns false if the pool is full.
 template <int CAP>
 __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32_t *ids, const double *val, int n,
-                             double ratio_lin, bool by_node, uint16_t *order) {
+                             double ratio_lin, bool by_node, uint16_t *order, int topk = 0) {
     for (int j = threadIdx.x; j < n; j += 64) {
         const double v = val[j];
         const uint32_t id = ids[j];
@@ -73,7 +73,9 @@ __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32
     }
     __syncthreads();
     int keep = 0;
-    if (n > 0) {
+    if (topk > 0) {
+        keep = topk < n ? topk : n;  // to_mapping(n_active_nodes): the k best whatever their value (hint.rs:124-131)
+    } else if (n > 0) {
         const double p0 = val[order[0]];
         int c = 0;
         for (int j = threadIdx.x; j < n; j += 64) c += (val[j] > 0.0 && val[j] > p0 * ratio_lin) ? 1 : 0;
@@ -94,7 +96,7 @@ __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32
     for (int j = threadIdx.x; j < keep; j += 64) {
         const int s = order[j];
         oid[j] = ids[s];
-        olp[j] = log(val[s]);
+        olp[j] = val[s] > 0.0 ? log(val[s]) : -INFINITY;
     }
     __syncthreads();
     return true;
@@ -124,6 +126,10 @@ struct SparseBwdArgs {
     const uint32_t *lanes;
     double ratio_lin;
     uint32_t *err;
+    // list mode (backward_with_mapping, backward.rs:59-93): B.tables[i] over mapping.nodes(i); no dense head
+    const uint64_t *list_off;   // [total_pos+1] (global positions) or null
+    const uint32_t *list_nodes;
+    int topk;        // > 0: to_mapping(topk) instead of to_mapping_by_score_ratio
     int mode;        // 0: start at the last position from b_init; 1: resume from the hand-off slot
     int *stop;       // [lanes] in (mode 1): position to compute next; out: see below
     BHandoff *hand;  // [lanes]
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             const double w = ok ? exp((double)fr.E * SP_LN2 - logP) * lp.p_end : 0.0;
             for (int j = lane; j < fr.n; j += 64) val[j] = w * (fr.m[j] + fr.i[j] + fr.d[j]);
             __syncthreads();
-            if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
+            if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, false, order, a.topk))
                 err |= SP_ERR_POOL;
         }
     } else {
@@ -198,12 +204,23 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             stop_at = pos;
             break;
         }
-        for (int j = lane; j < fr.n; j += 64) val[j] = fr.m[j] + fr.i[j] + fr.d[j];
-        __syncthreads();
-        sort_desc<CAP>(val, fr.n, order);
-        __syncthreads();
-        const int nl = fr.na < fr.n ? fr.na : fr.n;
-        for (int j = lane; j < nl; j += 64) list[j] = fr.id[order[j]];
+        int nl;
+        if (a.list_off) {
+            const uint64_t l0 = a.list_off[q0 + (uint64_t)pos];
+            nl = (int)(a.list_off[q0 + (uint64_t)pos + 1] - l0);
+            if (nl > CAP) {
+                err |= SP_ERR_CAPACITY;
+                break;
+            }
+            for (int j = lane; j < nl; j += 64) list[j] = a.list_nodes[l0 + j];
+        } else {
+            for (int j = lane; j < fr.n; j += 64) val[j] = fr.m[j] + fr.i[j] + fr.d[j];
+            __syncthreads();
+            sort_desc<CAP>(val, fr.n, order);
+            __syncthreads();
+            nl = fr.na < fr.n ? fr.na : fr.n;
+            for (int j = lane; j < nl; j += 64) list[j] = fr.id[order[j]];
+        }
         __syncthreads();
         Col<CAP> &prev = cols[(pos + 1) & 1];
         Col<CAP> &cur = cols[pos & 1];
@@ -216,10 +233,13 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             val[j] = bs >= 0 ? w * (fr.m[j] * cur.m[bs] + fr.i[j] * cur.i[bs] + fr.d[j] * cur.d[bs]) : 0.0;
         }
         __syncthreads();
-        if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, false, order))
+        if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, false, order, a.topk))
             err |= SP_ERR_POOL;
     }
-    if (stopped && !err) {
+    if (a.list_off) {
+        if (stopped) err |= SP_ERR_CAPACITY;  // a forward record is missing or larger than the list class
+        if (lane == 0) a.stop[gi] = stopped ? stop_at : s0;
+    } else if (stopped && !err) {
         // park B.tables[stop_at + 1] for the next phase
         if (have_cols && stop_at < len) {
             const Col<CAP> &c = cols[(stop_at + 1) & 1];
@@ -714,11 +734,9 @@ __global__ void __launch_bounds__(BLOCK) map_node_freq(const uint32_t *sorted_no
     freq[v] = s;
 }
 
-// PHMMModel::generate_mappings(reads, None, use_max_ratio = true)
-void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq) {
+static void init_sink(phmm_model *m, const phmm_reads *reads, MappingSink &sink) {
     hipStream_t s = current_stream();
     const uint64_t n_pos = reads->total;
-    MappingSink sink{};
     sink.reads = reads;
     sink.total_pos = n_pos;
     sink.cap = std::max<uint64_t>(m->ws_aux[5].bytes, n_pos * 160 + (1u << 20));
@@ -730,11 +748,12 @@ void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappi
     sink.mp.top = m->ws_aux[6].as<unsigned long long>();
     sink.mp.off = (uint64_t *)(m->ws_aux[6].as<char>() + 8);
 
-    std::vector<double> lf(reads->R);
-    double tot = 0.0;
-    full_prob_reads_sparse(m, reads, lf.data(), &tot, &sink);
-    trace("forward+backward chunks");
+}
 
+static void finish_mappings(phmm_model *m, const phmm_reads *reads, MappingSink &sink, const std::vector<double> &lf,
+                            phmm_mappings **out, double *out_node_freq) {
+    hipStream_t s = current_stream();
+    const uint64_t n_pos = reads->total;
     std::unique_ptr<phmm_mappings> mp(new phmm_mappings());
     mp->R = reads->R;
     mp->total_pos = n_pos;
@@ -797,6 +816,129 @@ void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappi
         trace("node freqs");
     }
     *out = mp.release();
+}
+
+// PHMMModel::generate_mappings(reads, None, use_max_ratio = true)
+void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq) {
+    MappingSink sink{};
+    init_sink(m, reads, sink);
+    std::vector<double> lf(reads->R);
+    double tot = 0.0;
+    full_prob_reads_sparse(m, reads, lf.data(), &tot, &sink);
+    trace("forward+backward chunks");
+    finish_mappings(m, reads, sink, lf, out, out_node_freq);
+}
+
+// PHMMModel::generate_mappings(reads, Some(mappings), use_max_ratio): run_with_mapping
+// (freq.rs:72-76) = forward_with_mapping (forward.rs:51-75) + backward_with_mapping
+// (backward.rs:59-93), then to_mapping_by_score_ratio / to_mapping(n_active) (hint.rs:124-142).
+void generate_mappings_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp_in, int use_max_ratio,
+                              phmm_mappings **out, double *out_node_freq) {
+    hipStream_t s = current_stream();
+    const uint64_t R = reads->R, n_pos = reads->total;
+    MappingSink sink{};
+    init_sink(m, reads, sink);
+    {   // every output list is a subset of its input list: the pool bound is exact
+        const uint64_t need = n_pos * 16 + mp_in->total_entries * 12 + (1u << 20);
+        if (need > sink.cap) {
+            sink.cap = need;
+            m->ws_aux[5].reserve(sink.cap);
+            sink.mp.base = m->ws_aux[5].as<uint8_t>();
+            sink.mp.cap = sink.cap;
+        }
+    }
+    upload_reads(reads);
+    upload_mappings(mp_in);
+    // forward_with_mapping with one record per position
+    DevBuf &fpool = m->ws_aux[1], &fmeta = m->ws_aux[2];
+    RecPool fp{};
+    fp.cap = (n_pos * 24 + mp_in->total_entries * 28) * 3 + (1u << 20);  // a read may be redone in up to 3 capacity classes
+    fpool.reserve(fp.cap);
+    fmeta.reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1));
+    HIP_CHECK(hipMemsetAsync(fmeta.p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1), s));
+    fp.base = fpool.as<uint8_t>();
+    fp.top = fmeta.as<unsigned long long>();
+    fp.off = (uint64_t *)(fmeta.as<char>() + 8);
+    std::vector<double> lf(R);
+    double tot = 0.0;
+    full_prob_reads_hinted(m, reads, mp_in, 1, nullptr, nullptr, lf.data(), &tot, &fp);
+
+    // backward_with_mapping + emit probs, one wave per read (W = 1 "lanes" = reads)
+    const int Lb = (int)reads->max_len;
+    DevBuf &ctl = m->ws_aux[3];
+    size_t cb = 0;
+    auto carve = [&](size_t bytes) {
+        cb = (cb + 255) / 256 * 256;
+        size_t o = cb;
+        cb += bytes;
+        return o;
+    };
+    const size_t o_len = carve(sizeof(int) * R), o_sw = carve(sizeof(int) * R), o_stop = carve(sizeof(int) * R),
+                 o_err = carve(sizeof(uint32_t) * R), o_lanes = carve(sizeof(uint32_t) * R), o_logp = carve(sizeof(double) * R),
+                 o_bases = carve((size_t)R * Lb), o_hand = carve(sizeof(BHandoff));
+    ctl.reserve(cb);
+    char *cp = (char *)ctl.p;
+    HIP_CHECK(hipMemsetAsync(cp, 0, o_bases, s));
+    std::vector<int> hlen(R);
+    std::vector<uint8_t> hb((size_t)R * Lb, 0xff);
+    for (uint64_t r = 0; r < R; r++) {
+        const uint64_t len = reads->off[r + 1] - reads->off[r];
+        hlen[r] = (int)len;
+        std::memcpy(hb.data() + (size_t)r * Lb, reads->bases.data() + reads->off[r], len);
+    }
+    HIP_CHECK(hipMemcpyAsync(cp + o_len, hlen.data(), sizeof(int) * R, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(cp + o_logp, lf.data(), sizeof(double) * R, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(cp + o_bases, hb.data(), hb.size(), hipMemcpyHostToDevice, s));
+    SparseBwdArgs ba{};
+    ba.M = sparse_model_of(m);
+    ba.d.N = (int)m->N;
+    ba.d.len = (const int *)(cp + o_len);
+    ba.d.logPf = (double *)(cp + o_logp);
+    ba.W = 1;
+    ba.Lb = Lb;
+    ba.sw = (const int *)(cp + o_sw);
+    ba.bases = (const uint8_t *)(cp + o_bases);
+    ba.fpool = fp;
+    ba.lane_pos0 = reads->d_off.as<uint64_t>();
+    ba.map_pos0 = reads->d_off.as<uint64_t>();
+    ba.lanes = (const uint32_t *)(cp + o_lanes);
+    ba.ratio_lin = std::exp(-m->params.active_node_max_ratio);
+    ba.err = (uint32_t *)(cp + o_err);
+    ba.list_off = mp_in->d_pos_off.as<uint64_t>();
+    ba.list_nodes = mp_in->d_nodes.as<uint32_t>();
+    ba.topk = use_max_ratio ? 0 : (int)m->params.n_active_nodes;
+    ba.mode = 0;
+    ba.stop = (int *)(cp + o_stop);
+    ba.hand = (BHandoff *)(cp + o_hand);
+    std::vector<uint32_t> cls[2];
+    for (uint64_t r = 0; r < R; r++) cls[mp_in->read_max_list[r] <= 64 ? 0 : 1].push_back((uint32_t)r);
+    for (int attempt = 0;; attempt++) {
+        ba.mpool = sink.mp;
+        for (int c = 0; c < 2; c++) {
+            if (cls[c].empty()) continue;
+            HIP_CHECK(hipMemcpyAsync(cp + o_lanes, cls[c].data(), sizeof(uint32_t) * cls[c].size(), hipMemcpyHostToDevice, s));
+            if (c == 0) hipLaunchKernelGGL((sparse_backward_kernel<64>), dim3((unsigned)cls[c].size()), dim3(64), 0, s, ba);
+            else hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)cls[c].size()), dim3(64), 0, s, ba);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(s));  // the lane list is reused by the next class
+        }
+        std::vector<uint32_t> herr(R);
+        HIP_CHECK(hipMemcpy(herr.data(), cp + o_err, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
+        bool pool_full = false;
+        for (uint64_t r = 0; r < R; r++) {
+            if (herr[r] & SP_ERR_POOL) pool_full = true;
+            else if (herr[r]) PHMM_THROW(PHMM_EINTERNAL, "backward_with_mapping error " + std::to_string(herr[r]));
+        }
+        if (!pool_full) break;
+        if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "mapping pool keeps overflowing");
+        sink.cap *= 2;
+        m->ws_aux[5].reserve(sink.cap);  // nothing to keep: every record is rewritten
+        const unsigned long long zero = 0;
+        HIP_CHECK(hipMemcpy(sink.mp.top, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        sink.mp.base = m->ws_aux[5].as<uint8_t>();
+        sink.mp.cap = sink.cap;
+    }
+    finish_mappings(m, reads, sink, lf, out, out_node_freq);
 }
 
 }  // namespace phmm

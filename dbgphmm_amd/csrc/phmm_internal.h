@@ -219,10 +219,15 @@ void model_upload(phmm_model *m);        // closures + device arrays
 // dense driver (dense.hip)
 void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb,
                double *out_nf);
+struct RecPool;
 // sparse / hinted drivers (sparse.hip)
 void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
                             const double *init_logp, const double *trans_logp, double *out_logp,
-                            double *out_total);
+                            double *out_total, const RecPool *pool = nullptr);
+void upload_reads(const phmm_reads *r);
+void upload_mappings(const phmm_mappings *mp);
+void generate_mappings_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp_in, int use_max_ratio,
+                              phmm_mappings **out, double *out_node_freq);
 struct MappingSink;
 void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total,
                             MappingSink *sink);

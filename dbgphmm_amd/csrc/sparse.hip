@@ -11,7 +11,7 @@
 #include <cstring>
 #include <numeric>
 
-#include "sparse_dev.h"
+#include "sparse_dyn.h"
 
 namespace phmm {
 
@@ -28,6 +28,7 @@ struct HintedArgs {
     uint64_t R;
     double *out_logp;  // [C][R]
     uint32_t *err;     // [C][R]
+    RecPool pool;      // optional (forward_with_mapping, forward.rs:51-75): one record per position, candidate 0 only
 };
 
 template <int CAP, int LPN>
@@ -61,6 +62,7 @@ __global__ void __launch_bounds__(64) hinted_score_kernel(const HintedArgs a) {
         }
         err |= fwd_list_step<CAP, LPN>(M, cols[(pos + 1) & 1], cols[pos & 1], a.map_nodes + o0, n, a.bases[b0 + pos],
                                        pos == 0, pos, lnk_slot, lnk_w, dA, dB);
+        if (a.pool.base && cand == 0 && !store_record_col<CAP>(a.pool, b0 + pos, cols[pos & 1])) err |= SP_ERR_POOL;
     }
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
     const double lp = err ? NAN : col_log_end(M, cols[(len - 1) & 1]);
@@ -78,8 +80,6 @@ __global__ void __launch_bounds__(256) exp_kernel(const double *in, double *out,
     }
 }
 
-namespace {
-
 void upload_reads(const phmm_reads *r) {
     if (r->on_device) return;
     r->d_bases.upload(r->bases.data(), r->bases.size());
@@ -94,6 +94,8 @@ void upload_mappings(const phmm_mappings *mp) {
     HIP_CHECK(hipStreamSynchronize(current_stream()));
     mp->on_device = true;
 }
+
+namespace {
 
 SparseModel sparse_model(const phmm_model *m) {
     const ModelDev &d = m->dev;
@@ -146,7 +148,7 @@ template <int CAP, int LPN> void launch_hinted(const HintedArgs &a, uint32_t n_r
 
 void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
                             const double *init_logp, const double *trans_logp, double *out_logp,
-                            double *out_total) {
+                            double *out_total, const RecPool *pool) {
     hipStream_t s = current_stream();
     CallStats &st = stats();
     st = CallStats();
@@ -208,6 +210,7 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
     a.R = R;
     a.out_logp = d_out.as<double>();
     a.err = d_err.as<uint32_t>();
+    if (pool) a.pool = *pool;
 
     EvTimer tm(timing_enabled());
     for (int c = 0; c < 3; c++) {
@@ -226,6 +229,7 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
             uint32_t e = 0;
             for (uint32_t k = 0; k < n_cand; k++) e |= h_err[(size_t)k * R + rd];
             if (!e) continue;
+            if (e & SP_ERR_POOL) PHMM_THROW(PHMM_EINTERNAL, "forward record pool exhausted");
             if (e & SP_ERR_DUPLICATE) PHMM_THROW(PHMM_EINVAL, "duplicate node in a mapping list");
             if ((e & (SP_ERR_LINKS | SP_ERR_CAPACITY)) && c < 2) cls[c + 1].push_back(rd);
             else PHMM_THROW(PHMM_ECAPACITY, "mapping list needs more than 400 slots / 8 in-list parents");

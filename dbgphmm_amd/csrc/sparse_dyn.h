@@ -53,6 +53,32 @@ template <int CAP> __device__ bool store_record(const RecPool &p, uint64_t pos_i
     return true;
 }
 
+// a Col (list column of the hinted flow: every entry carries m, i and d) as a forward record
+template <int CAP> __device__ bool store_record_col(const RecPool &p, uint64_t pos_index, const Col<CAP> &c) {
+    const int n = c.n;
+    const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
+    const uint64_t bytes = 16 + idb + (uint64_t)(3 * n) * 8;
+    const uint64_t o = pool_alloc(p, bytes);
+    if (o + bytes > p.cap) return false;
+    uint8_t *rec = p.base + o;
+    if (threadIdx.x == 0) {
+        ((uint32_t *)rec)[0] = (uint32_t)n;
+        ((uint32_t *)rec)[1] = (uint32_t)n;
+        ((int *)rec)[2] = c.E;
+        ((uint32_t *)rec)[3] = 0;
+        p.off[pos_index] = o + 8;
+    }
+    uint32_t *ids = (uint32_t *)(rec + 16);
+    double *m = (double *)(rec + 16 + idb), *i = m + n, *d = i + n;
+    for (int j = threadIdx.x; j < n; j += 64) {
+        ids[j] = c.id[j];
+        m[j] = c.m[j];
+        i[j] = c.i[j];
+        d[j] = c.d[j];
+    }
+    return true;
+}
+
 inline SparseModel sparse_model_of(const phmm_model *m) {
     const ModelDev &d = m->dev;
     SparseModel s{};

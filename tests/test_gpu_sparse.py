@@ -134,7 +134,7 @@ def test_adaptive_sparse_top_k_mode_is_rejected(gpu_lib, oracle):
         D.PHMMModel(arrays).to_full_prob_reads(D.ReadCollection(reads), None, False)
 
 
-def _compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6):
+def _compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6, top_k=0):
     gpo, gnd, glp = gpu_arrays
     opo, ond, olp = orc_arrays
     assert gpo.shape == opo.shape
@@ -157,9 +157,11 @@ def _compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6):
             assert sorted(gn[:ka].tolist()) == sorted(on[:kb].tolist()), (i, gn, on)
             od = dict(zip(on[:kb].tolist(), ol[:kb].tolist()))
             assert all(abs(od[n] - l) < tol for n, l in zip(gn[:ka].tolist(), gl[:ka].tolist())), (i, gn, gl, on, ol)
-            # lists are sorted descending and respect the ratio
-            assert np.all(np.diff(gl) <= 1e-12)
-            if a1 > a0:
+            # lists are sorted descending and respect the ratio / the fixed size
+            assert np.all(np.diff(gl[np.isfinite(gl)]) <= 1e-12)
+            if top_k:
+                assert a1 - a0 == b1 - b0 <= top_k
+            elif a1 > a0:
                 assert gl[0] - gl[-1] < 30.0 + 1e-9
             g += 1
 
@@ -200,3 +202,32 @@ def test_generate_mappings_matches_oracle(gpu_lib, oracle, cfg):
     _, lp_sparse = gm.to_full_prob_reads(rc, None)
     long_enough = np.array([len(r) >= 2 * k for r in reads])
     assert np.max(np.abs(lp_hint - lp_sparse)[long_enough], initial=0.0) < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [(600, 12, 0.01, 3, 24, True, 40), (900, 16, 0.003, 21, 40, True, 40),
+                                 (600, 12, 0.01, 5, 16, False, 6), (300, 12, 0.001, 9, 12, False, 40)])
+def test_generate_mappings_from_mappings_matches_oracle(gpu_lib, oracle, cfg):
+    """generate_mappings(reads, Some(mappings), use_max_ratio) = run_with_mapping (freq.rs:72-76:
+    forward_with_mapping + backward_with_mapping) + to_mapping_by_score_ratio / to_mapping(n_active)
+    (hint.rs:193-220)."""
+    gl, k, p, seed, n_reads, use_ratio, n_active = cfg
+    arrays, sg = small_dbg_model(gl, k, p, seed=seed, min_copy_num=1)
+    arrays.param = arrays.param.with_(n_active_nodes=n_active)
+    reads = D.sample_reads(arrays, 10 ** 9, 150, seed=seed + 1, max_reads=n_reads)
+    reads = [r[: max(1, len(r) - (j * 13) % 149)] for j, r in enumerate(reads)]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    omp0, _ = om.generate_mappings(reads, None, True, n_threads=8)
+    gmp0 = D.Mappings.from_arrays(rc, *omp0)
+    mp, nf = gm.generate_mappings(rc, gmp0, use_ratio)
+    omp, onf = om.generate_mappings(reads, omp0, use_ratio, n_threads=8)
+    _compare_mappings(reads, mp.arrays(), omp, top_k=0 if use_ratio else n_active)
+    assert np.max(np.abs(nf - onf)) < 1e-6
+    # the forward score of the pass that produced them is kept with the mappings
+    olp = om.full_prob_reads(reads, omp0, True, n_threads=8)
+    assert np.max(np.abs(mp.read_logp()[1] - olp)) < TOL_LOGP
+    # device-resident round trip: mappings made on the GPU feed the next call without a host copy
+    mp1, _ = gm.generate_mappings(rc, None, True)
+    mp2, nf2 = gm.generate_mappings(rc, mp1, True)
+    omp2, onf2 = om.generate_mappings(reads, om.generate_mappings(reads, None, True, n_threads=8)[0], True, n_threads=8)
+    assert abs(nf2.sum() - onf2.sum()) < 1e-6
