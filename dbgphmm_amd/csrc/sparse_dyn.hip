@@ -35,6 +35,31 @@ struct WarmArgs {
     int n_warmup, threshold;
 };
 
+// reads (resident, concatenated) -> bases transposed to [group][pos][W]; 0xff past the end / padding lanes
+struct StageArgs {
+    const uint8_t *bases;
+    const uint64_t *off;
+    const uint32_t *order;  // slot -> read id for the chunk's first slot onwards
+    uint32_t n_slots;
+    int W, Lc, Lfull;
+    uint8_t *out_dense, *out_full;
+};
+__global__ void __launch_bounds__(BLOCK) stage_bases(const StageArgs sa) {
+    const int g = blockIdx.y;
+    const unsigned t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (unsigned)sa.Lfull * sa.W) return;
+    const int i = (int)(t / sa.W), r = (int)(t % sa.W);
+    const uint32_t slot = (uint32_t)g * sa.W + r;
+    uint8_t b = 0xff;
+    if (slot < sa.n_slots) {
+        const uint32_t rd = sa.order[slot];
+        const uint64_t o0 = sa.off[rd], o1 = sa.off[rd + 1];
+        if ((uint64_t)i < o1 - o0) b = sa.bases[o0 + i];
+    }
+    sa.out_full[((size_t)g * sa.Lfull + i) * sa.W + r] = b;
+    if (i < sa.Lc) sa.out_dense[((size_t)g * sa.Lc + i) * sa.W + r] = b;
+}
+
 // count (and collect) the nodes of dense column `col` with total > tmax * exp(-ratio)
 template <int W>
 __global__ void __launch_bounds__(BLOCK) col_count(const WarmArgs wa, const int col) {
@@ -265,6 +290,9 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     base.npt = plan.npt;
     base.eall = 0;
     base.want_freq = 0;
+    upload_reads(reads);
+    DevBuf &d_order = m->ws_aux[15];
+    d_order.upload(plan.order.data(), sizeof(uint32_t) * plan.order.size());
     int g0 = 0;
     while (g0 < plan.ng_total) {
         const uint32_t r0 = plan.order[(size_t)g0 * W];
@@ -304,34 +332,40 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         HIP_CHECK(hipMemsetAsync(wp, 0, o_cnode, s));
         HIP_CHECK(hipMemsetAsync(wp + o_sw, 0xff, sizeof(int) * lanes, s));  // sw = -1
 
-        // host staging (the full-length transposed bases are needed by the sparse kernel)
+        // staging on the device: the reads are resident (phmm_reads), the kernels want the bases
+        // transposed to [group][pos][W] (dense: the Lc kept columns; sparse: the full length)
         trace("chunk setup");
-        std::vector<uint8_t> hb((size_t)ngc * Lc * W, 0xff), hbf((size_t)ngc * Lfull * W, 0xff);
         std::vector<int> hl((size_t)lanes, 0);
         uint64_t dense_cells = 0;
-        for (int g = 0; g < ngc; g++)
-            for (int r = 0; r < W; r++) {
-                const size_t slot = (size_t)(g0 + g) * W + r;
-                if (slot >= R) continue;
-                const uint32_t rd = plan.order[slot];
-                const uint64_t len = reads->off[rd + 1] - reads->off[rd];
-                hl[(size_t)g * W + r] = (int)len;
-                for (uint64_t i = 0; i < len; i++) {
-                    const uint8_t b = reads->bases[reads->off[rd] + i];
-                    if ((int)i < Lc) hb[((size_t)g * Lc + i) * W + r] = b;
-                    hbf[((size_t)g * Lfull + i) * W + r] = b;
-                }
-            }
+        for (int gi = 0; gi < lanes; gi++) {
+            const size_t slot = (size_t)g0 * W + gi;
+            if (slot >= R) continue;
+            const uint32_t rd = plan.order[slot];
+            hl[gi] = (int)(reads->off[rd + 1] - reads->off[rd]);
+        }
         std::vector<double> hib;
         host_logib(m, (size_t)Lc, hib);
         // the dense kernels see lengths clamped to the kept columns; the true lengths are
         // restored for the sparse kernel below
         std::vector<int> hlc(hl);
         for (auto &v : hlc) v = std::min(v, Lc);
-        HIP_CHECK(hipMemcpyAsync((void *)a.bases, hb.data(), hb.size(), hipMemcpyHostToDevice, s));
+        {
+            StageArgs sa{};
+            sa.bases = reads->d_bases.as<uint8_t>();
+            sa.off = reads->d_off.as<uint64_t>();
+            sa.order = d_order.as<uint32_t>() + (size_t)g0 * W;
+            sa.n_slots = (uint32_t)(R - std::min<uint64_t>(R, (uint64_t)g0 * W));
+            sa.W = W;
+            sa.Lc = Lc;
+            sa.Lfull = Lfull;
+            sa.out_dense = (uint8_t *)a.bases;
+            sa.out_full = (uint8_t *)(wp + o_bases);
+            const unsigned per_group = (unsigned)Lfull * W;
+            hipLaunchKernelGGL(stage_bases, dim3((per_group + BLOCK - 1) / BLOCK, ngc), dim3(BLOCK), 0, s, sa);
+            HIP_CHECK(hipGetLastError());
+        }
         HIP_CHECK(hipMemcpyAsync((void *)a.len, hlc.data(), hlc.size() * sizeof(int), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync((void *)a.logib, hib.data(), hib.size() * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(wp + o_bases, hbf.data(), hbf.size(), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipStreamSynchronize(s));
 
         WarmArgs wa{};
