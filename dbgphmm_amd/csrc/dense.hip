@@ -94,22 +94,40 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
     const int r = threadIdx.x % W;
     const int row = threadIdx.x / W;
     const int len = a.len[g * W + r];
-    const bool newcol = pos < len;
-    const bool have_prev = pos >= 1 && pos <= len;
+    // warm-up: a lane whose switch to the sparse frontier is decided takes no further dense column
+    const bool active = a.wf_sw == nullptr || a.wf_sw[g * W + r] < 0;
+    const bool newcol = active && pos < len;
+    const bool have_prev = active && pos >= 1 && pos <= len;
     const bool fin = have_prev && pos == len;
+    if (!__syncthreads_or(newcol || have_prev)) return;  // the whole read group is done
     const LinParams &lp = a.lp;
     const size_t NW = (size_t)a.N * W;
 
     int Epos = 0;
     double sc = 1.0, isc = 1.0, ibs = 0.0;
+    double thrL = INFINITY, thrU = INFINITY;  // warm-up count thresholds (scaled domain)
+    bool collect = false;
     if (have_prev) {
+        // column maximum over the nodes (cmaxF) and the InsBegin value of column pos-1, both in that
+        // column's stored exponent: the rescale keeps either below 1
         const unsigned long long cm = a.cmaxF[((size_t)g * a.Lc + (pos - 1)) * W + r];
-        const int e = exp_of_bits(cm);
+        const int Eprev = a.FE[((size_t)g * (a.Lc + 1) + (pos - 1)) * W + r];
+        const double ib_st = exp(a.logib[pos - 1] - (double)Eprev * LN2);
+        const unsigned long long ibb = (unsigned long long)__double_as_longlong(ib_st);
+        const int e = exp_of_bits(cm > ibb ? cm : ibb);
         sc = pow2(-e);
         isc = pow2(e);
-        Epos = a.FE[((size_t)g * (a.Lc + 1) + (pos - 1)) * W + r] + e;
+        Epos = Eprev + e;
         // fib, forward.rs:541-545 (read-independent chain, log domain on the host)
         ibs = exp(a.logib[pos - 1] - (double)Epos * LN2);
+        if (a.wf_sw) {
+            // max over nodes of the column total t = m+i+d lies in [L, U]:
+            //   L = max(m,i) (t >= its m and i);  U = ub_a * max(m,i) + ub_b * p_ID * ib  (closure weights)
+            const double cmF = __longlong_as_double((long long)cm) * sc;
+            thrL = cmF * a.wf_ratio;
+            thrU = (a.wf_ub_a * cmF + a.wf_ub_b * lp.p_ID * ibs) * (1.0 + 1e-9) * a.wf_ratio;
+            collect = a.wf_mode[g * W + r] != 0;
+        }
     }
     const uint8_t x = newcol ? a.bases[((size_t)g * a.Lc + pos) * W + r] : (uint8_t)0;
 
@@ -120,6 +138,7 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
     double *ci_ = a.Fi + ((size_t)g * a.Lc + (pos < a.Lc ? pos : 0)) * NW;
 
     double vmax = 0.0, esum = 0.0, tmax = 0.0;
+    int nsub = 0;
     const bool want_e = fin || (a.eall && have_prev);
     if (lb < a.nblk) {
         // Each row of W lanes walks a RUN of npt consecutive node ids.  On a unitig run
@@ -212,8 +231,21 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
                 pd[ik] = dprev * isc;  // stored in column pos-1's own exponent
                 mnew = pe * (lp.p_MM * m1 + lp.p_IM * i1 + lp.p_DM * td + nr.init * cb);
                 inew = lp.p_random * (lp.p_MI * om + lp.p_II * oi + lp.p_DI * dprev);
-                if (want_e) esum += om + oi + dprev;
-                tmax = fmax(tmax, om + oi + dprev);
+                const double tk = om + oi + dprev;
+                if (want_e) esum += tk;
+                tmax = fmax(tmax, tk);
+                if (tk > thrL) {
+                    // (rare) inside the score ratio of the column maximum, as far as this launch can tell
+                    nsub += tk > thrU ? 1 : 0;
+                    if (collect) {
+                        const int gi = g * W + r;
+                        const int slot = atomicAdd(&a.wf_cnt[gi], 1);
+                        if (slot < WF_CAP) {
+                            a.wf_node[(size_t)gi * WF_CAP + slot] = (uint32_t)k;
+                            a.wf_tot[(size_t)gi * WF_CAP + slot] = tk * isc;
+                        }
+                    }
+                }
                 // slide the window: this node becomes "k-1" of the next one
 #pragma unroll
                 for (int h = H - 1; h >= 1; h--) wg[h] = wg[h - 1];
@@ -230,10 +262,7 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
           }
         }
     }
-    // column maximum -> next launch's rescale.  The InsBegin value joins the maximum so
-    // that it can never overflow the scaled domain.
-    if (newcol && lb == 0 && row == 0 && pos >= 1) vmax = fmax(vmax, lp.p_random * lp.p_II * ibs);
-    if (newcol && lb == 0 && row == 0 && pos == 0) vmax = fmax(vmax, lp.p_random * lp.p_MI);
+    // column maximum over the nodes -> next launch's rescale (which also looks at the InsBegin value)
     const double bm = block_reduce_rows<W>(vmax, OpMax(), lds);
     if (threadIdx.x < W && newcol && lb < a.nblk)
         atomicMax(&a.cmaxF[((size_t)g * a.Lc + pos) * W + r], (unsigned long long)__double_as_longlong(bm));
@@ -243,6 +272,10 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
         const double bt = block_reduce_rows<W>(tmax * isc, OpMax(), lds);
         if (threadIdx.x < W && have_prev && lb < a.nblk)
             atomicMax(&a.tmaxF[((size_t)g * a.Lc + (pos - 1)) * W + r], (unsigned long long)__double_as_longlong(bt));
+    }
+    if (a.wf_sw) {
+        const double bn = block_reduce_rows<W>((double)nsub, OpAdd(), lds);
+        if (threadIdx.x < W && bn > 0.0) atomicAdd(&a.wf_sub[g * W + r], (int)bn);
     }
     if (a.eall || __syncthreads_or(fin)) {
         const double bs = block_reduce_rows<W>(esum, OpAdd(), lds);

@@ -50,7 +50,18 @@ struct DenseArgs {
     int want_map;                  // keep the per-node emit probs of the column in Pa/Pb
     double *Pa, *Pb;               // [ng][N][W] emit probs of merged index pos / len
     unsigned long long *pmax;      // [ng][Lc+1][W] their maxima, by merged index
+    // dense warm-up of the adaptive sparse forward (sparse_dyn.hip): launch pos also counts the nodes of
+    // column pos-1 inside the score ratio (top_nodes_by_score_ratio, table.rs:134-149) -- see WarmFuse
+    const int *wf_sw;              // [ng][W] switch position (-1 = still dense); null: off.  Decided lanes are skipped
+    const uint8_t *wf_mode;        // [ng][W] 1: collect the candidates of this lane in this launch
+    int *wf_sub;                   // [ng][W] nodes certainly inside the ratio (total > U * ratio)
+    int *wf_cnt;                   // [ng][W] nodes possibly inside (total > L * ratio) = slots used in wf_node/wf_tot
+    uint32_t *wf_node;             // [ng][W][WF_CAP]
+    double *wf_tot;                // [ng][W][WF_CAP] totals in the column's stored exponent
+    double wf_ratio;               // exp(-active_node_max_ratio)
+    double wf_ub_a, wf_ub_b;       // column total <= wf_ub_a * max(m,i) + wf_ub_b * p_ID * ib   (model.cpp)
 };
+static constexpr int WF_CAP = 1024;
 
 
 struct Plan {

@@ -117,6 +117,7 @@ void model_upload(phmm_model *m) {
     std::vector<FwdEntry> fc;
     std::vector<BwdEntry> bc;
     std::vector<double> dinit(N), tdinit(N);
+    double max_sd = 0.0, max_dinit = 0.0;
     fc.reserve((size_t)N * 7);
     bc.reserve((size_t)N * 7);
     std::vector<FwdEntry> tmpf;
@@ -145,6 +146,12 @@ void model_upload(phmm_model *m) {
                      });
         dinit[k] = di;
         tdinit[k] = tdi;
+        {   // bound of a column total by the column's max(m,i) and InsBegin (warm-up count, dense.hip)
+            double sd = 0.0;
+            for (const auto &e : tmpf) sd += e.wD;
+            max_sd = std::max(max_sd, sd);
+            max_dinit = std::max(max_dinit, di);
+        }
         uint32_t flags = 0;
         // unitig run: ancestors are exactly k-1 .. k-H, every path weight 1
         if (chain_ok && k >= (uint32_t)H && tmpf.size() == (size_t)H) {
@@ -207,6 +214,8 @@ void model_upload(phmm_model *m) {
     d.nodes.upload(nodes.data(), sizeof(NodeRec) * N);
     d.emis.upload(m->emission.data(), N);
     d.init.upload(ilin.data(), sizeof(double) * N);
+    m->wf_ub_a = 2.0 + (l.p_MD + l.p_ID) * max_sd;
+    m->wf_ub_b = max_dinit;
     d.dinit.upload(dinit.data(), sizeof(double) * N);
     d.tdinit.upload(tdinit.data(), sizeof(double) * N);
     d.fc_off.upload(fc_off.data(), sizeof(uint32_t) * (N + 1));

@@ -135,6 +135,7 @@ struct phmm_model {
     std::vector<uint32_t> par_off, par_node, par_edge, chi_off, chi_node, chi_edge;
     std::vector<double> logib;  // forward InsBegin chain, log domain (forward.rs:541-545)
     phmm::ModelDev dev;
+    double wf_ub_a = 0.0, wf_ub_b = 0.0;  // column total <= ub_a * max(m,i) + ub_b * p_ID * ib (model.cpp)
     // grow-only workspaces
     phmm::DevBuf ws_tables, ws_misc, ws_out;
     phmm::DevBuf ws_aux[16];  // per-call scratch kept across calls (no hipMalloc in the steady state)

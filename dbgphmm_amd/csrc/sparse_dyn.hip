@@ -31,6 +31,8 @@ struct WarmArgs {
     double *cand_tot;          // [ng][W][400]
     int *cand_n;               // [ng][W] candidates kept for the switch column
     int *undecided;            // [1]
+    int *amb;                  // [ng][W] 1: the fused count of fwd_step could not settle this lane's column
+    int *n_amb;                // [1]
     double ratio_lin;          // exp(-active_node_max_ratio)
     int n_warmup, threshold;
 };
@@ -70,8 +72,9 @@ __global__ void __launch_bounds__(BLOCK) col_count(const WarmArgs wa, const int 
     const int r = threadIdx.x % W, row = threadIdx.x / W;
     const int gi = g * W + r;
     const int len = a.len[gi];
-    const bool live = wa.sw[gi] < 0 && col < len;
+    const bool live = wa.sw[gi] < 0 && col < len && wa.amb[gi] != 0;
     if (lb >= a.nblk) return;
+    if (!__syncthreads_or(live)) return;
     const size_t NW = (size_t)a.N * W;
     const double *fm = a.Fm + ((size_t)g * a.Lc + col) * NW;
     const double *fi = a.Fi + ((size_t)g * a.Lc + col) * NW;
@@ -121,7 +124,7 @@ __global__ void __launch_bounds__(BLOCK) warm_decide(const WarmArgs wa, const in
         wa.sw[gi] = 0;
         return;
     }
-    if (wa.sw[gi] >= 0) return;
+    if (wa.sw[gi] >= 0 || !wa.amb[gi]) return;
     bool decided = false;
     if (pos >= len) {
         wa.sw[gi] = len;  // all columns were dense
@@ -137,6 +140,76 @@ __global__ void __launch_bounds__(BLOCK) warm_decide(const WarmArgs wa, const in
     }
     if (!decided) atomicAdd(wa.undecided, 1);
     wa.cnt[gi] = 0;
+}
+
+// The same decision from the counts that fwd_step gathered while it wrote column pos-1's Del values
+// (dense.hip): one wave per lane.  fwd_step could only bracket the column maximum T of the totals,
+// L <= T <= U, so it counted `sub` = #{t > U*ratio} (certainly inside the ratio) and, for lanes in
+// collect mode, stored every (node, t) with t > L*ratio (a superset).  Now T is known:
+//   * superset complete (<= WF_CAP entries): filter it with T*ratio -> the exact list and count;
+//   * else sub > threshold: the column stays dense whatever the exact count is;
+//   * else the lane is flagged ambiguous and the exact col_count + warm_decide pair settles it.
+__global__ void __launch_bounds__(BLOCK) warm_decide_fused(const WarmArgs wa, const int pos, const int total_lanes, const int W) {
+    const int gi = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (gi >= total_lanes) return;
+    const int len = wa.d.len[gi];
+    if (len == 0) {
+        if (lane == 0) wa.sw[gi] = 0;
+        return;
+    }
+    if (wa.sw[gi] >= 0) return;
+    const int nsub = wa.d.wf_sub[gi], cn = wa.d.wf_cnt[gi];
+    const bool collected = wa.d.wf_mode[gi] != 0 && cn <= WF_CAP;
+    bool decided = false, amb = false;
+    int new_sw = -1, new_cn = 0;
+    if (pos >= len) {
+        new_sw = len;  // all columns were dense
+        decided = true;
+    } else if (pos >= 1) {
+        const bool forced = pos >= wa.n_warmup;
+        if (collected) {
+            const int g = gi / W, r = gi % W;
+            const double tmax = __longlong_as_double((long long)wa.d.tmaxF[((size_t)g * wa.d.Lc + (pos - 1)) * W + r]);
+            const double thr = tmax * wa.ratio_lin;
+            int c = 0;
+            for (int base = 0; base < cn; base += 64) {
+                const int j = base + lane;
+                const double t = j < cn ? wa.d.wf_tot[(size_t)gi * WF_CAP + j] : 0.0;
+                const bool ok = j < cn && t > 0.0 && t > thr;
+                const unsigned long long mask = __ballot(ok);
+                const int slot = c + __popcll(mask & ((1ull << lane) - 1ull));
+                if (ok && slot < PHMM_MAX_ACTIVE_NODES) {
+                    wa.cand_node[(size_t)gi * PHMM_MAX_ACTIVE_NODES + slot] = wa.d.wf_node[(size_t)gi * WF_CAP + j];
+                    wa.cand_tot[(size_t)gi * PHMM_MAX_ACTIVE_NODES + slot] = t;
+                }
+                c += __popcll(mask);
+            }
+            const int ntop = c < PHMM_MAX_ACTIVE_NODES ? c : PHMM_MAX_ACTIVE_NODES;  // ArrayVec capacity
+            if (forced || ntop <= wa.threshold) {
+                new_sw = pos;
+                new_cn = c;
+                decided = true;
+            }
+        } else if (!forced && (nsub < PHMM_MAX_ACTIVE_NODES ? nsub : PHMM_MAX_ACTIVE_NODES) > wa.threshold) {
+            // certainly more than `threshold` nodes inside the ratio: dense
+        } else {
+            amb = true;
+        }
+    }
+    if (lane == 0) {
+        if (decided) {
+            wa.sw[gi] = new_sw;
+            if (new_sw < len) wa.cand_n[gi] = new_cn;
+        }
+        wa.amb[gi] = amb ? 1 : 0;
+        if (amb) atomicAdd(wa.n_amb, 1);
+        else if (!decided) atomicAdd(wa.undecided, 1);
+        // collect the next column's candidates once the count has come down far enough
+        ((uint8_t *)wa.d.wf_mode)[gi] = (!decided && pos >= 1 && nsub <= 4096) ? 1 : 0;
+        wa.d.wf_sub[gi] = 0;
+        wa.d.wf_cnt[gi] = 0;
+    }
 }
 
 // Forced switch (pos >= n_warmup) with more than 400 nodes inside the ratio: the reference's
@@ -321,11 +394,15 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             return o;
         };
         const size_t o_sw = carve(sizeof(int) * lanes), o_cnt = carve(sizeof(int) * lanes),
-                     o_cn = carve(sizeof(int) * lanes), o_und = carve(sizeof(int)),
+                     o_cn = carve(sizeof(int) * lanes), o_und = carve(sizeof(int) * 2),
+                     o_amb = carve(sizeof(int) * lanes), o_wsub = carve(sizeof(int) * lanes),
+                     o_wcnt = carve(sizeof(int) * lanes), o_mode = carve((size_t)lanes),
                      o_cnode = carve(sizeof(uint32_t) * (size_t)lanes * PHMM_MAX_ACTIVE_NODES),
                      o_ctot = carve(sizeof(double) * (size_t)lanes * PHMM_MAX_ACTIVE_NODES),
                      o_lanes = carve(sizeof(uint32_t) * lanes), o_out = carve(sizeof(double) * lanes),
                      o_err = carve(sizeof(uint32_t) * lanes),
+                     o_wnode = carve(sizeof(uint32_t) * (size_t)lanes * WF_CAP),
+                     o_wtot = carve(sizeof(double) * (size_t)lanes * WF_CAP),
                      o_bases = carve((size_t)ngc * Lfull * W);
         warm.reserve(wb);
         char *wp = (char *)warm.p;
@@ -374,6 +451,18 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         wa.cnt = (int *)(wp + o_cnt);
         wa.cand_n = (int *)(wp + o_cn);
         wa.undecided = (int *)(wp + o_und);
+        wa.n_amb = wa.undecided + 1;
+        wa.amb = (int *)(wp + o_amb);
+        a.wf_sw = wa.sw;
+        a.wf_mode = (const uint8_t *)(wp + o_mode);
+        a.wf_sub = (int *)(wp + o_wsub);
+        a.wf_cnt = (int *)(wp + o_wcnt);
+        a.wf_node = (uint32_t *)(wp + o_wnode);
+        a.wf_tot = (double *)(wp + o_wtot);
+        a.wf_ratio = std::exp(-prm.active_node_max_ratio);
+        a.wf_ub_a = m->wf_ub_a;
+        a.wf_ub_b = m->wf_ub_b;
+        wa.d = a;
         wa.cand_node = (uint32_t *)(wp + o_cnode);
         wa.cand_tot = (double *)(wp + o_ctot);
         wa.ratio_lin = std::exp(-prm.active_node_max_ratio);
@@ -389,13 +478,21 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             launch_fwd_step(W, a, pos);  // column pos (if pos < Lc), d + totals maximum of column pos-1
             lt.end();
             st.launches[0]++;
-            if (pos >= 1) launch_col_count_w(W, wa, pos - 1);
-            HIP_CHECK(hipMemsetAsync(wa.undecided, 0, sizeof(int), s));
-            hipLaunchKernelGGL(warm_decide, dim3((lanes + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, wa, pos, lanes);
-            int und = 0;
-            HIP_CHECK(hipMemcpyAsync(&und, wa.undecided, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemsetAsync(wa.undecided, 0, sizeof(int) * 2, s));
+            hipLaunchKernelGGL(warm_decide_fused, dim3((lanes + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, s, wa, pos,
+                               lanes, W);
+            int und[2] = {0, 0};
+            HIP_CHECK(hipMemcpyAsync(und, wa.undecided, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
-            if (und == 0) break;
+            if (und[1] > 0) {
+                // lanes the fused count could not settle: exact count of column pos-1, then the plain decision
+                launch_col_count_w(W, wa, pos - 1);
+                hipLaunchKernelGGL(warm_decide, dim3((lanes + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, wa, pos, lanes);
+                HIP_CHECK(hipMemcpyAsync(und, wa.undecided, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                st.launches[3]++;
+            }
+            if (und[0] == 0) break;
             if (pos >= Lc) PHMM_THROW(PHMM_EINTERNAL, "warm-up did not terminate");
         }
         st.ms[0] += lt.total_ms();
