@@ -21,6 +21,23 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 hipStream_t current_stream() { return g_stream; }
+int &workset_index() {
+    static thread_local int idx = 0;
+    return idx;
+}
+ThreadContext capture_thread_context() {
+    ThreadContext c{g_ws_limit, g_timing, 0};
+    (void)hipGetDevice(&c.device);
+    return c;
+}
+void adopt_thread_context(const ThreadContext &c, hipStream_t stream, int workset) {
+    (void)hipSetDevice(c.device);
+    g_ws_limit = c.ws_limit;
+    g_timing = c.timing;
+    g_stream = stream;
+    g_stats = CallStats();
+    workset_index() = workset;
+}
 CallStats &stats() { return g_stats; }
 bool timing_enabled() { return g_timing; }
 
@@ -37,7 +54,9 @@ void trace(const char *tag) {
     static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
     (void)hipStreamSynchronize(g_stream);
     const auto now = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[phmm trace] %-28s %8.2f ms\n", tag,
+    static const auto t0 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[phmm trace] w%d @%9.2f %-28s %8.2f ms\n", workset_index(),
+                 std::chrono::duration<double, std::milli>(now - t0).count(), tag,
                  std::chrono::duration<double, std::milli>(now - last).count());
     last = now;
 }
@@ -248,7 +267,12 @@ int phmm_model_set_params(phmm_model *m, const phmm_params *params) {
 }
 uint32_t phmm_model_n_nodes(const phmm_model *m) { return m ? m->N : 0; }
 uint32_t phmm_model_n_edges(const phmm_model *m) { return m ? m->E : 0; }
-void phmm_model_destroy(phmm_model *m) { delete m; }
+void phmm_model_destroy(phmm_model *m) {
+    if (!m) return;
+    for (auto &ws : m->wstream)
+        if (ws) (void)hipStreamDestroy(ws);
+    delete m;
+}
 
 int phmm_reads_create(const uint8_t *bases, const uint64_t *offsets, uint64_t R, phmm_reads **out) {
     phmm_reads *r = nullptr;

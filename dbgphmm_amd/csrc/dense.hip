@@ -825,7 +825,7 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
     st = CallStats();
     const int W = plan.W;
     const size_t NW = (size_t)m->N * W;
-    const uint64_t limit = table_budget(m->ws_tables.bytes);
+    const uint64_t limit = table_budget(m->wset().tables.bytes);
 
     DenseArgs base{};
     fill_model_args(base, m);
@@ -856,11 +856,11 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
         a.Lc = Lc;
         size_t tb = 0, mb = 0;
         layout(a, W, full_b, nullptr, nullptr, tb, mb);
-        m->ws_tables.reserve(tb);
-        m->ws_misc.reserve(mb);
-        layout(a, W, full_b, m->ws_tables.p, m->ws_misc.p, tb, mb);
+        m->wset().tables.reserve(tb);
+        m->wset().misc.reserve(mb);
+        layout(a, W, full_b, m->wset().tables.p, m->wset().misc.p, tb, mb);
         a.tmaxF = nullptr;  // only the adaptive sparse warm-up needs the per-column totals maximum
-        HIP_CHECK(hipMemsetAsync(m->ws_misc.p, 0, mb, s));
+        HIP_CHECK(hipMemsetAsync(m->wset().misc.p, 0, mb, s));
 
         // host staging: transposed bases, lengths, logib
         std::vector<uint8_t> hb((size_t)ngc * Lc * W, 0xff);

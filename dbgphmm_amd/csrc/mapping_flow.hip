@@ -513,7 +513,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         else hb[gi] = hl[gi] - 1;
         pos_max = std::max(pos_max, hb[gi] & ~(1 << 30));
     }
-    DevBuf &ctl = m->ws_aux[3], &pbuf = m->ws_aux[4];
+    DevBuf &ctl = m->wset().aux[3], &pbuf = m->wset().aux[4];
     size_t cb = 0;
     auto carve = [&](size_t bytes) {
         cb = (cb + 255) / 256 * 256;
@@ -640,6 +640,8 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.ratio_lin = mc.ratio_lin;
         ma.err = (uint32_t *)(cp + o_err);
         LaunchTimer lt(timing_enabled());
+        std::unique_lock<std::mutex> dense_lock;
+        if (mc.dense_token) dense_lock = std::unique_lock<std::mutex>(*mc.dense_token);
         for (int pos = pos_max; pos >= 0; pos--) {
             lt.begin();
             launch_bwd_step(W, a, pos);
@@ -655,6 +657,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         std::vector<uint32_t> herr(lanes);
         HIP_CHECK(hipMemcpyAsync(herr.data(), cp + o_err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        if (dense_lock.owns_lock()) dense_lock.unlock();
         trace("  dense backward+collect");
         bool pool_full = false;
         for (int gi = 0; gi < lanes; gi++) {
@@ -662,18 +665,9 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             else if (herr[gi]) PHMM_THROW(PHMM_EINTERNAL, "mapping backward error " + std::to_string(herr[gi]));
         }
         if (!pool_full) break;
-        if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "mapping pool keeps overflowing");
-        // grow the pool: keep what earlier chunks wrote, drop this chunk's partial output
-        DevBuf bigger;
-        bigger.reserve(sink->cap * 2);
-        if (top_before) HIP_CHECK(hipMemcpyAsync(bigger.p, sink->mp.base, top_before, hipMemcpyDeviceToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(sink->mp.top, &top_before, sizeof(top_before), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        std::swap(bigger.p, m->ws_aux[5].p);
-        std::swap(bigger.bytes, m->ws_aux[5].bytes);
-        sink->cap *= 2;
-        sink->mp.base = m->ws_aux[5].as<uint8_t>();
-        sink->mp.cap = sink->cap;
+        // the pool is shared by every chunk in flight: the whole call restarts with a bigger one
+        (void)attempt;
+        throw SinkOverflow{};
     }
 }
 
@@ -739,14 +733,14 @@ static void init_sink(phmm_model *m, const phmm_reads *reads, MappingSink &sink)
     const uint64_t n_pos = reads->total;
     sink.reads = reads;
     sink.total_pos = n_pos;
-    sink.cap = std::max<uint64_t>(m->ws_aux[5].bytes, n_pos * 160 + (1u << 20));
-    m->ws_aux[5].reserve(sink.cap);
-    m->ws_aux[6].reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1));
-    HIP_CHECK(hipMemsetAsync(m->ws_aux[6].p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1), s));
-    sink.mp.base = m->ws_aux[5].as<uint8_t>();
+    sink.cap = std::max<uint64_t>(m->wset().aux[5].bytes, n_pos * 160 + (1u << 20));
+    m->wset().aux[5].reserve(sink.cap);
+    m->wset().aux[6].reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1));
+    HIP_CHECK(hipMemsetAsync(m->wset().aux[6].p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1), s));
+    sink.mp.base = m->wset().aux[5].as<uint8_t>();
     sink.mp.cap = sink.cap;
-    sink.mp.top = m->ws_aux[6].as<unsigned long long>();
-    sink.mp.off = (uint64_t *)(m->ws_aux[6].as<char>() + 8);
+    sink.mp.top = m->wset().aux[6].as<unsigned long long>();
+    sink.mp.off = (uint64_t *)(m->wset().aux[6].as<char>() + 8);
 
 }
 
@@ -762,7 +756,7 @@ static void finish_mappings(phmm_model *m, const phmm_reads *reads, MappingSink 
     mp->host_valid = false;
     mp->trusted = true;
     // counts -> exclusive scan -> compaction, all on the device
-    DevBuf &cnt = m->ws_aux[13], &tmp = m->ws_aux[14];
+    DevBuf &cnt = m->wset().aux[13], &tmp = m->wset().aux[14];
     cnt.reserve(sizeof(uint64_t) * (n_pos + 1));
     mp->d_pos_off.reserve(sizeof(uint64_t) * (n_pos + 1));
     const unsigned nb = (unsigned)((n_pos + 1 + BLOCK - 1) / BLOCK);
@@ -821,10 +815,19 @@ static void finish_mappings(phmm_model *m, const phmm_reads *reads, MappingSink 
 // PHMMModel::generate_mappings(reads, None, use_max_ratio = true)
 void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq) {
     MappingSink sink{};
-    init_sink(m, reads, sink);
     std::vector<double> lf(reads->R);
     double tot = 0.0;
-    full_prob_reads_sparse(m, reads, lf.data(), &tot, &sink);
+    for (int attempt = 0;; attempt++) {
+        init_sink(m, reads, sink);
+        try {
+            full_prob_reads_sparse(m, reads, lf.data(), &tot, &sink);
+            break;
+        } catch (const SinkOverflow &) {
+            if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "mapping pool keeps overflowing");
+            HIP_CHECK(hipDeviceSynchronize());
+            m->wset().aux[5].reserve(sink.cap * 2);  // init_sink sizes the pool from the buffer
+        }
+    }
     trace("forward+backward chunks");
     finish_mappings(m, reads, sink, lf, out, out_node_freq);
 }
@@ -842,15 +845,15 @@ void generate_mappings_hinted(phmm_model *m, const phmm_reads *reads, const phmm
         const uint64_t need = n_pos * 16 + mp_in->total_entries * 12 + (1u << 20);
         if (need > sink.cap) {
             sink.cap = need;
-            m->ws_aux[5].reserve(sink.cap);
-            sink.mp.base = m->ws_aux[5].as<uint8_t>();
+            m->wset().aux[5].reserve(sink.cap);
+            sink.mp.base = m->wset().aux[5].as<uint8_t>();
             sink.mp.cap = sink.cap;
         }
     }
     upload_reads(reads);
     upload_mappings(mp_in);
     // forward_with_mapping with one record per position
-    DevBuf &fpool = m->ws_aux[1], &fmeta = m->ws_aux[2];
+    DevBuf &fpool = m->wset().aux[1], &fmeta = m->wset().aux[2];
     RecPool fp{};
     fp.cap = (n_pos * 24 + mp_in->total_entries * 28) * 3 + (1u << 20);  // a read may be redone in up to 3 capacity classes
     fpool.reserve(fp.cap);
@@ -865,7 +868,7 @@ void generate_mappings_hinted(phmm_model *m, const phmm_reads *reads, const phmm
 
     // backward_with_mapping + emit probs, one wave per read (W = 1 "lanes" = reads)
     const int Lb = (int)reads->max_len;
-    DevBuf &ctl = m->ws_aux[3];
+    DevBuf &ctl = m->wset().aux[3];
     size_t cb = 0;
     auto carve = [&](size_t bytes) {
         cb = (cb + 255) / 256 * 256;
@@ -932,10 +935,10 @@ void generate_mappings_hinted(phmm_model *m, const phmm_reads *reads, const phmm
         if (!pool_full) break;
         if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "mapping pool keeps overflowing");
         sink.cap *= 2;
-        m->ws_aux[5].reserve(sink.cap);  // nothing to keep: every record is rewritten
+        m->wset().aux[5].reserve(sink.cap);  // nothing to keep: every record is rewritten
         const unsigned long long zero = 0;
         HIP_CHECK(hipMemcpy(sink.mp.top, &zero, sizeof(zero), hipMemcpyHostToDevice));
-        sink.mp.base = m->ws_aux[5].as<uint8_t>();
+        sink.mp.base = m->wset().aux[5].as<uint8_t>();
         sink.mp.cap = sink.cap;
     }
     finish_mappings(m, reads, sink, lf, out, out_node_freq);

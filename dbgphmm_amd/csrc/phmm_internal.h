@@ -30,6 +30,16 @@ struct Error {
     } while (0)
 
 hipStream_t current_stream();
+// workspace set of the calling thread (0 unless the thread is a pipeline worker)
+int &workset_index();
+// a pipeline worker adopts the API thread's per-call settings with its own stream and workspace set
+struct ThreadContext {
+    uint64_t ws_limit;
+    bool timing;
+    int device;
+};
+ThreadContext capture_thread_context();
+void adopt_thread_context(const ThreadContext &c, hipStream_t stream, int workset);
 uint64_t workspace_limit();
 // DP-table budget of a call on model buffers that already hold `owned` bytes
 uint64_t table_budget(size_t owned);
@@ -137,8 +147,22 @@ struct phmm_model {
     phmm::ModelDev dev;
     double wf_ub_a = 0.0, wf_ub_b = 0.0;  // column total <= ub_a * max(m,i) + ub_b * p_ID * ib (model.cpp)
     // grow-only workspaces
-    phmm::DevBuf ws_tables, ws_misc, ws_out;
-    phmm::DevBuf ws_aux[16];  // per-call scratch kept across calls (no hipMalloc in the steady state)
+    // One set per pipeline worker (sparse_dyn.hip runs chunks of read groups concurrently on their own
+    // streams); the API thread and single-stream paths use set 0.  aux[] = per-call scratch kept across
+    // calls (no hipMalloc in the steady state).
+    struct WorkSet {
+        phmm::DevBuf tables, misc, aux[16];
+    };
+    static constexpr int MAX_WORKERS = 4;
+    WorkSet wsets[MAX_WORKERS];
+    hipStream_t wstream[MAX_WORKERS] = {};  // worker streams, created on first use
+    phmm::DevBuf ws_out;
+    WorkSet &wset() { return wsets[phmm::workset_index()]; }
+    size_t owned_table_bytes() const {
+        size_t b = 0;
+        for (const auto &w : wsets) b += w.tables.bytes;
+        return b;
+    }
 };
 
 struct phmm_reads {

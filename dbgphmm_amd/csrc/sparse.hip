@@ -161,7 +161,7 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
     ensure_logib(m, reads->max_len + 1);
 
     // candidate probabilities in the linear domain: [C][N], [C][E]
-    DevBuf &cand_init = m->ws_aux[7], &cand_trans = m->ws_aux[8], &staging = m->ws_aux[9];
+    DevBuf &cand_init = m->wset().aux[7], &cand_trans = m->wset().aux[8], &staging = m->wset().aux[9];
     const double *d_init = m->dev.init.as<double>();
     const double *d_trans = m->dev.trans_lin.as<double>();
     if (init_logp) {
@@ -190,7 +190,7 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
         const uint32_t mx = mp->read_max_list[r];
         cls[mx <= 64 ? 0 : (mx <= 128 ? 1 : 2)].push_back((uint32_t)r);
     }
-    DevBuf &d_ids = m->ws_aux[10], &d_out = m->ws_aux[11], &d_err = m->ws_aux[12];
+    DevBuf &d_ids = m->wset().aux[10], &d_out = m->wset().aux[11], &d_err = m->wset().aux[12];
     d_ids.reserve(R * sizeof(uint32_t));
     d_out.reserve((size_t)n_cand * R * sizeof(double));
     d_err.reserve((size_t)n_cand * R * sizeof(uint32_t));

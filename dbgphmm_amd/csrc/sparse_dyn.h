@@ -2,6 +2,8 @@
 // (backward_by_forward + mapping extraction).
 #pragma once
 
+#include <mutex>
+
 #include "frontier_dev.h"
 
 namespace phmm {
@@ -108,6 +110,7 @@ namespace phmm {
 // Device-side collector of the mapping lists of all reads: one record pool for the whole call,
 // record offsets indexed by the GLOBAL read position (reads->off[read] + i), so the final CSR is
 // produced on the device (counts -> scan -> compaction) without a host pass over positions.
+struct SinkOverflow {};  // thrown by a chunk when the shared mapping pool is full: the call restarts with a bigger one
 struct MappingSink {
     RecPool mp;
     uint64_t cap;
@@ -132,6 +135,7 @@ struct MapChunk {
     double *d_logp_sparse;
     uint32_t *cand_node;  // [lanes][400] scratch
     double *cand_tot;
+    std::mutex *dense_token;  // held while the chunk runs its HBM-bound dense backward (sparse_dyn.hip)
 };
 
 void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_lanes, MappingSink *sink,

@@ -17,6 +17,13 @@
 #include <cstring>
 
 #include "dense_internal.h"
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <memory>
+#include <mutex>
+#include <thread>
+
 #include "frontier_dev.h"
 #include "sparse_dyn.h"
 #include "sparse_fwd_kernel.h"
@@ -335,55 +342,107 @@ void launch_col_count_w(int W, const WarmArgs &wa, int col) {
 // PHMMModel::to_full_prob_reads without mappings: forward_sparse_score_only(use_max_ratio = true)
 void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total,
                             MappingSink *sink) {
-    hipStream_t s = current_stream();
-    CallStats &st = stats();
-    st = CallStats();
+    stats() = CallStats();
     const uint64_t R = reads->R;
     if (m->dev.max_degree > 8)
         PHMM_THROW(PHMM_EINVAL, "sparse path supports node degree <= 8 (MultiDbg MAX_DEGREE is 5)");
     ensure_logib(m, reads->max_len + 1);
     const phmm_params &prm = m->params;
     std::vector<double> lf(R, 0.0);
-    DevBuf &warm = m->ws_aux[0];  // per-chunk warm-up control arrays
-    DevBuf &fpool = m->ws_aux[1], &fpool_meta = m->ws_aux[2];  // forward table records (generate_mappings)
-
-    // Dense columns kept per read group: the switch normally happens after ~log4(N/200) + a few
-    // columns, far before n_warmup.  The first pass keeps 20; the few reads that are still dense
-    // there (e.g. a read that starts with errors) are deferred to a second, small pass that keeps
-    // all n_warmup+2 columns.
-    auto run_plan = [&](const Plan &plan, const int64_t lc_cap, std::vector<uint32_t> *deferred) {
-    const int W = plan.W;
-    const size_t NW = (size_t)m->N * W;
-    const uint64_t limit = table_budget(m->ws_tables.bytes);
-    const uint64_t R = plan.order.size();  // reads of THIS plan (slots beyond it are padding)
-    DenseArgs base{};
-    fill_model_args(base, m);
-    base.nblk = plan.nblk;
-    base.nblk8 = plan.nblk8;
-    base.npt = plan.npt;
-    base.eall = 0;
-    base.want_freq = 0;
     upload_reads(reads);
-    DevBuf &d_order = m->ws_aux[15];
-    d_order.upload(plan.order.data(), sizeof(uint32_t) * plan.order.size());
-    int g0 = 0;
-    while (g0 < plan.ng_total) {
-        const uint32_t r0 = plan.order[(size_t)g0 * W];
-        const int Lfull = (int)(reads->off[r0 + 1] - reads->off[r0]);
-        // dense columns kept: at most n_warmup (+1 so that the launch that writes d of the last
-        // dense column has somewhere to put its speculative next column)
-        const int Lc = (int)std::min<int64_t>(Lfull, std::min<int64_t>(prm.n_warmup + 2, lc_cap));
-        const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8;
-        int ngc = (int)std::min<uint64_t>(plan.ng_total - g0, std::max<uint64_t>(1, limit / std::max<size_t>(per_group, 1)));
+
+    // ---- work items.  A plan is a grouping of reads (W per group, longest first); it is cut into
+    // chunks of read groups whose dense warm-up tables fit the worker's share of HBM.  Dense columns
+    // kept per read group: the switch normally happens after ~log4(N/200) + a few columns, far before
+    // n_warmup.  The first plan keeps 20; the few reads that are still dense there (e.g. a read that
+    // starts with errors) are deferred to a small plan of their own that keeps all n_warmup+2 columns.
+    //
+    // Chunks are independent, and each one alternates between HBM-bound phases (dense warm-up, dense
+    // backward) and latency-bound ones (one wave per read on the sparse frontier): up to MAX_WORKERS
+    // host threads, each with its own stream and workspace set, run different chunks concurrently so
+    // that the dense phase of one chunk fills the machine while another walks its frontiers.
+    struct PlanCtx {
+        Plan plan;
+        int64_t lc_cap;
+        bool may_defer;
+        DevBuf d_order;
+    };
+    struct Item {
+        PlanCtx *pc;
+        int g0, ngc, Lc, Lfull;
+    };
+    std::mutex mu;
+    // HBM-bound phases (dense warm-up, dense backward) run one at a time: a single dense kernel already
+    // saturates the memory system, so overlapping two only interleaves their streams; the latency-bound
+    // sparse phases of the other workers run underneath whichever chunk holds the token.
+    std::mutex dense_token;
+    std::condition_variable cv;
+    std::deque<Item> queue;
+    std::vector<std::unique_ptr<PlanCtx>> plans;
+    int active = 0;
+    std::exception_ptr first_error;
+    int n_workers = 3;
+    if (const char *e = std::getenv("PHMM_WORKERS")) n_workers = std::max(1, std::min(phmm_model::MAX_WORKERS, std::atoi(e)));
+    int chunk_groups = 0;  // 0: automatic
+    if (const char *e = std::getenv("PHMM_CHUNK_GROUPS")) chunk_groups = std::max(0, std::atoi(e));
+    const uint64_t limit_total = table_budget(m->owned_table_bytes());
+
+    // cut a plan into items (caller holds `mu` or is the only thread)
+    auto enqueue_plan = [&](std::unique_ptr<PlanCtx> pcu) {
+        PlanCtx *pc = pcu.get();
+        const Plan &plan = pc->plan;
+        const int W = plan.W;
+        const size_t NW = (size_t)m->N * W;
+        pc->d_order.upload(plan.order.data(), sizeof(uint32_t) * plan.order.size());
+        HIP_CHECK(hipStreamSynchronize(current_stream()));
+        int target = chunk_groups;
+        if (target == 0) target = n_workers > 1 ? std::max(4, (plan.ng_total + 3 * n_workers - 1) / (3 * n_workers)) : plan.ng_total;
+        const uint64_t limit = limit_total / (uint64_t)n_workers;
+        int g0 = 0;
+        while (g0 < plan.ng_total) {
+            const uint32_t r0 = plan.order[(size_t)g0 * W];
+            const int Lfull = (int)(reads->off[r0 + 1] - reads->off[r0]);
+            // dense columns kept: at most n_warmup (+1 so that the launch that writes d of the last
+            // dense column has somewhere to put its speculative next column)
+            const int Lc = (int)std::min<int64_t>(Lfull, std::min<int64_t>(prm.n_warmup + 2, pc->lc_cap));
+            const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8;
+            int ngc = (int)std::min<uint64_t>(plan.ng_total - g0, std::max<uint64_t>(1, limit / std::max<size_t>(per_group, 1)));
+            ngc = std::min(ngc, std::max(1, target));
+            queue.push_back(Item{pc, g0, ngc, Lc, Lfull});
+            g0 += ngc;
+        }
+        plans.push_back(std::move(pcu));
+    };
+
+    auto run_chunk = [&](const Item &it) {
+        hipStream_t s = current_stream();
+        CallStats &st = stats();
+        DevBuf &warm = m->wset().aux[0];  // per-chunk warm-up control arrays
+        DevBuf &fpool = m->wset().aux[1], &fpool_meta = m->wset().aux[2];  // forward table records (generate_mappings)
+        const Plan &plan = it.pc->plan;
+        const DevBuf &d_order = it.pc->d_order;
+        const int W = plan.W;
+        const uint64_t R = plan.order.size();  // reads of THIS plan (slots beyond it are padding)
+        const int g0 = it.g0, ngc = it.ngc, Lc = it.Lc, Lfull = it.Lfull;
+        std::vector<uint32_t> deferred_ids;
+        std::vector<uint32_t> *deferred = it.pc->may_defer ? &deferred_ids : nullptr;
+        DenseArgs base{};
+        fill_model_args(base, m);
+        base.nblk = plan.nblk;
+        base.nblk8 = plan.nblk8;
+        base.npt = plan.npt;
+        base.eall = 0;
+        base.want_freq = 0;
+        {
         DenseArgs a = base;
         a.ng = ngc;
         a.Lc = Lc;
         size_t tb = 0, mb = 0;
         layout(a, W, false, nullptr, nullptr, tb, mb);
-        m->ws_tables.reserve(tb);
-        m->ws_misc.reserve(mb);
-        layout(a, W, false, m->ws_tables.p, m->ws_misc.p, tb, mb);
-        HIP_CHECK(hipMemsetAsync(m->ws_misc.p, 0, mb, s));
+        m->wset().tables.reserve(tb);
+        m->wset().misc.reserve(mb);
+        layout(a, W, false, m->wset().tables.p, m->wset().misc.p, tb, mb);
+        HIP_CHECK(hipMemsetAsync(m->wset().misc.p, 0, mb, s));
         const int lanes = ngc * W;
         // warm-up control
         size_t wb = 0;
@@ -473,6 +532,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         // ---- dense warm-up with per-read switch decisions
         int pos = 0;
         LaunchTimer lt(timing_enabled());
+        std::unique_lock<std::mutex> dense_lock(dense_token);
         for (;; pos++) {
             lt.begin();
             launch_fwd_step(W, a, pos);  // column pos (if pos < Lc), d + totals maximum of column pos-1
@@ -496,6 +556,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             if (pos >= Lc) PHMM_THROW(PHMM_EINTERNAL, "warm-up did not terminate");
         }
         st.ms[0] += lt.total_ms();
+        dense_lock.unlock();
         trace("dense warm-up");
         // reads that ended inside the warm-up: fe of their last (dense) column
         launch_fwd_finish(W, a);
@@ -672,6 +733,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 mc.d_logp_sparse = fa.out_logp;
                 mc.cand_node = wa.cand_node;
                 mc.cand_tot = wa.cand_tot;
+                mc.dense_token = &dense_token;
                 trace("sparse forward");
                 mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
                 trace("mapping backward total");
@@ -699,6 +761,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             mc.d_logp_sparse = (double *)(wp + o_out);
             mc.cand_node = wa.cand_node;
             mc.cand_tot = wa.cand_tot;
+                mc.dense_token = &dense_token;
             mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
         }
         for (int gi = 0; gi < lanes; gi++) {
@@ -707,19 +770,75 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             const uint32_t rd = plan.order[slot];
             lf[rd] = hsw[gi] < hl[gi] ? slp[gi] : tlf[gi];
         }
-        g0 += ngc;
-    }
-    };  // run_plan
+        }
+        if (!deferred_ids.empty()) {
+            std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan_ids(m, reads, deferred_ids), (int64_t)prm.n_warmup + 2, false, {}});
+            std::lock_guard<std::mutex> lk(mu);
+            enqueue_plan(std::move(pc));
+            cv.notify_all();
+        }
+    };  // run_chunk
 
-    std::vector<uint32_t> deferred;
+    auto worker_loop = [&]() {
+        for (;;) {
+            Item it{};
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !queue.empty() || active == 0 || first_error; });
+                if (first_error || queue.empty()) break;  // queue empty and nobody can add to it
+                it = queue.front();
+                queue.pop_front();
+                active++;
+            }
+            try {
+                run_chunk(it);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!first_error) first_error = std::current_exception();
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                active--;
+            }
+            cv.notify_all();
+        }
+    };
+
     {
-        Plan plan = make_plan(m, reads, 0);
-        run_plan(plan, 20, &deferred);
+        std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan(m, reads, 0), 20, true, {}});
+        // few groups: one worker (the calling thread, on the caller's stream)
+        int min_groups = 8;
+        if (const char *e = std::getenv("PHMM_PIPELINE_MIN_GROUPS")) min_groups = std::max(1, std::atoi(e));
+        if (pc->plan.ng_total < min_groups) n_workers = 1;
+        enqueue_plan(std::move(pc));
     }
-    if (!deferred.empty()) {
-        Plan plan2 = make_plan_ids(m, reads, deferred);
-        run_plan(plan2, prm.n_warmup + 2, nullptr);
+    const int n_threads = (int)std::min<size_t>((size_t)n_workers, queue.size());
+    if (n_threads <= 1) {
+        worker_loop();
+    } else {
+        HIP_CHECK(hipStreamSynchronize(current_stream()));  // uploads / memsets the chunks depend on
+        const ThreadContext ctx = capture_thread_context();
+        CallStats merged;
+        std::vector<std::thread> threads;
+        for (int t = 0; t < n_threads; t++) {
+            if (!m->wstream[t]) HIP_CHECK(hipStreamCreateWithFlags(&m->wstream[t], hipStreamNonBlocking));
+            threads.emplace_back([&, t]() {
+                adopt_thread_context(ctx, m->wstream[t], t);
+                worker_loop();
+                (void)hipStreamSynchronize(m->wstream[t]);
+                std::lock_guard<std::mutex> lk(mu);
+                const CallStats &ws = stats();
+                for (int k = 0; k < 4; k++) {
+                    merged.ms[k] += ws.ms[k];
+                    merged.launches[k] += ws.launches[k];
+                    merged.cells[k] += ws.cells[k];
+                }
+            });
+        }
+        for (auto &th : threads) th.join();
+        stats() = merged;
     }
+    if (first_error) std::rethrow_exception(first_error);
     double tot = 0.0;
     for (uint64_t r = 0; r < R; r++) tot += lf[r];
     put_doubles(out_logp, lf.data(), R);

@@ -231,3 +231,27 @@ def test_generate_mappings_from_mappings_matches_oracle(gpu_lib, oracle, cfg):
     mp2, nf2 = gm.generate_mappings(rc, mp1, True)
     omp2, onf2 = om.generate_mappings(reads, om.generate_mappings(reads, None, True, n_threads=8)[0], True, n_threads=8)
     assert abs(nf2.sum() - onf2.sum()) < 1e-6
+
+
+def test_chunk_pipeline_matches_single_stream(gpu_lib, oracle, monkeypatch):
+    """The sparse flow cuts the read groups into chunks that worker threads run concurrently on their
+    own streams (sparse_dyn.hip).  Forced here on a small read set: same mappings, same ln P."""
+    arrays, sg = small_dbg_model(900, 16, 0.003, seed=21, min_copy_num=1)
+    reads = D.sample_reads(arrays, 10 ** 9, 150, seed=5, max_reads=200)
+    reads = [r[: max(1, len(r) - (j * 13) % 149)] for j, r in enumerate(reads)]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    monkeypatch.setenv("PHMM_WORKERS", "1")
+    mp1, nf1 = gm.generate_mappings(rc, None, True)
+    _, lp1 = gm.to_full_prob_reads(rc, None, True)
+    monkeypatch.setenv("PHMM_WORKERS", "3")
+    monkeypatch.setenv("PHMM_CHUNK_GROUPS", "1")
+    monkeypatch.setenv("PHMM_PIPELINE_MIN_GROUPS", "2")
+    mp3, nf3 = gm.generate_mappings(rc, None, True)
+    _, lp3 = gm.to_full_prob_reads(rc, None, True)
+    a1, a3 = mp1.arrays(), mp3.arrays()
+    assert all(np.array_equal(x, y) for x, y in zip(a1, a3))
+    assert np.array_equal(lp1, lp3) and np.array_equal(nf1, nf3)
+    assert np.array_equal(mp1.read_logp()[1], mp3.read_logp()[1])
+    omp, onf = om.generate_mappings(reads, None, True, n_threads=8)
+    _compare_mappings(reads, a3, omp)
