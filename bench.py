@@ -58,7 +58,7 @@ def build_workload(name: str, rank: int):
 
 def cpu_baseline(arrays, reads, mode: str, budget_s: float = 20.0):
     """The oracle (C restatement of the reference; OpenMP over reads = the rayon stand-in) timed on
-    this box's host cores on a bounded sample of the same workload."""
+    this box's host cores on a bounded sample of the same workload (about `budget_s` seconds)."""
     from oracle import oracle as O
     O.build()
     om = O.Model(arrays)
@@ -70,17 +70,22 @@ def cpu_baseline(arrays, reads, mode: str, budget_s: float = 20.0):
         else:
             om.generate_mappings(sample, None, True, n_threads=threads)
 
-    probe = reads[0][: (60 if mode == "dense" else 120)]
-    t0 = time.time()
-    run([probe], 1)
-    t_probe = time.time() - t0
-    full = [r for r in reads if len(r) >= 0.9 * max(map(len, reads))][:cores] or list(reads[:cores])
+    full = [r for r in reads if len(r) >= 0.9 * max(map(len, reads))] or list(reads)
     if mode == "dense":
-        per_read = max(20, min(len(full[0]), int(budget_s / max(t_probe / len(probe), 1e-9))))
-        sample = [r[:per_read] for r in full]
+        # cost is proportional to bases: time a short prefix, then cut every read to fit the budget
+        probe = full[0][:60]
+        t0 = time.time()
+        run([probe], 1)
+        t_base = (time.time() - t0) / len(probe)
+        per_read = max(20, min(len(full[0]), int(budget_s / max(t_base, 1e-9))))
+        sample = [r[:per_read] for r in full[:cores]]
     else:
-        # cost is dominated by the ~14 dense warm-up columns of every read: keep whole reads
-        n = max(1, min(len(full), int(cores * budget_s / max(t_probe * 1.5, 1e-3))))
+        # cost is dominated by the dense warm-up columns of every read: keep whole reads, time one
+        # batch of `cores` reads and size the sample from it
+        t0 = time.time()
+        run(full[:cores], cores)
+        t_batch = time.time() - t0
+        n = int(cores * max(1.0, min(budget_s / max(t_batch, 1e-3), len(full) / cores)))
         sample = full[:n]
     t0 = time.time()
     run(sample, cores)
@@ -90,6 +95,20 @@ def cpu_baseline(arrays, reads, mode: str, budget_s: float = 20.0):
         "generate_mappings (sparse-adaptive forward + backward_by_forward + posteriors)"
     return {"value": nb / dt, "unit": "bases/s", "cores": cores, "kind": "port",
             "sample": f"{len(sample)} reads, {nb} bases of the same workload, {what}, {cores} OpenMP threads, {dt:.1f} s"}
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
+    (profiles/, made by tools/profile_r1.sh + tools/pmc_traffic.py: FETCH_SIZE / WRITE_SIZE in separate
+    passes, corrected with the calibration kernels of tools/pmc_calib.hip).  bench.py cannot collect
+    hardware counters itself; None when the summary is absent."""
+    path = os.environ.get("PHMM_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r1_cfg3_pmc_traffic.json"))
+    try:
+        doc = json.load(open(path))
+        k = doc["kernels"][kernel]
+        return float(k["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
 
 
 def main():
@@ -207,6 +226,7 @@ def main():
         # dominant kernel: bwd_step (backward column + fused F(.)B posterior): B write 24 + B prev read 24 +
         # F re-read 24 = 72 algorithmic bytes per cell; fwd_step: 24 + 24 = 48.
         rb, rf = roof(1, 72.0), roof(0, 48.0)
+        traffic, traffic_src = pmc_traffic("phmm::bwd_step<64>") if args.workload == "cfg3" else (None, None)
         out = {
             "metric": "read-bases/sec through forward+backward P(R|X)",
             "value": total_bases * args.steps / dt,
@@ -225,7 +245,9 @@ def main():
                        "parallelism": f"reads sharded over {world} GPU(s); one all-reduce of [sum lnP, node_freq[N]]",
                        **extra},
             "roofline": {"bound": "hbm", "achieved": rb["achieved"] if rb else 0.0, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (rb["achieved"] / 8000.0) if rb else 0.0, "traffic": None, "kernel": "bwd_step",
+                         "frac": (rb["achieved"] / 8000.0) if rb else 0.0, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src, "kernel": "bwd_step<64>",
+                         "algorithmic_bytes_per_launch": (72.0 * rb["cells_per_launch"]) if rb else None,
                          **({k: v for k, v in rb.items() if k != "achieved"} if rb else {}),
                          "fwd_step": rf},
         }

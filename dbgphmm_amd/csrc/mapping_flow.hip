@@ -266,14 +266,10 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             const Col<CAP> &c = cols[(s0 + 1) & 1];
             const size_t NW = (size_t)a.d.N * a.W;
             const int pc = (s0 + 1) & 1;
+            // (the host zeroed the chunk's B buffers before the sparse backward: a lane-strided clear
+            // from here would cost a 64-byte sector per 8-byte store)
             double *bm = a.d.Bm + ((size_t)g * a.d.bcols + pc) * NW;
             double *bi = a.d.Bi + ((size_t)g * a.d.bcols + pc) * NW;
-            for (int k = lane; k < a.d.N; k += 64) {
-                bm[(size_t)k * a.W + r] = 0.0;
-                bi[(size_t)k * a.W + r] = 0.0;
-            }
-            __threadfence();
-            __syncthreads();
             double mx = 0.0;
             for (int j = lane; j < c.n; j += 64) {
                 bm[(size_t)c.id[j] * a.W + r] = c.m[j];
@@ -554,6 +550,9 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         HIP_CHECK(hipMemsetAsync(a.cmaxB, 0, sizeof(unsigned long long) * (size_t)a.ng * a.Lc * W, s));
         HIP_CHECK(hipMemsetAsync(a.pmax, 0, sizeof(unsigned long long) * (size_t)a.ng * (a.Lc + 1) * W, s));
         HIP_CHECK(hipMemsetAsync(a.BE, 0, sizeof(int) * (size_t)a.ng * (a.Lc + 1) * W, s));
+        // the sparse backward hands B.tables[s0+1] over as a dense column: zeros except its own nodes
+        HIP_CHECK(hipMemsetAsync(a.Bm, 0, sizeof(double) * (size_t)a.ng * a.bcols * NW, s));
+        HIP_CHECK(hipMemsetAsync(a.Bi, 0, sizeof(double) * (size_t)a.ng * a.bcols * NW, s));
 
         if (!sparse_lanes.empty()) {
             // ln P of the sparse reads joins the dense ones (posterior weights)
@@ -639,7 +638,8 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.candB_val = (double *)(cp + o_bv);
         ma.ratio_lin = mc.ratio_lin;
         ma.err = (uint32_t *)(cp + o_err);
-        LaunchTimer lt(timing_enabled());
+        const bool st_on = W == 64;  // statistics of bwd_step<64> only (bench.py's roofline)
+        LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock;
         if (mc.dense_token) dense_lock = std::unique_lock<std::mutex>(*mc.dense_token);
         for (int pos = pos_max; pos >= 0; pos--) {
@@ -648,12 +648,12 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             lt.end();
             launch_post_collect_w(W, ma, pos);
             hipLaunchKernelGGL(emit_dense_map, dim3(lanes, 2), dim3(BLOCK), 0, s, ma, pos);
-            st.launches[1]++;
+            if (st_on) st.launches[1]++;
         }
         HIP_CHECK(hipGetLastError());
         st.ms[1] += lt.total_ms();
         for (int gi = 0; gi < lanes; gi++)
-            if (hb[gi] >= 0) st.cells[1] += (uint64_t)((hb[gi] & ~(1 << 30)) + 1) * m->N;
+            if (st_on && hb[gi] >= 0) st.cells[1] += (uint64_t)((hb[gi] & ~(1 << 30)) + 1) * m->N;
         std::vector<uint32_t> herr(lanes);
         HIP_CHECK(hipMemcpyAsync(herr.data(), cp + o_err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));

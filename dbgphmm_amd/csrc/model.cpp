@@ -237,6 +237,36 @@ void model_upload(phmm_model *m) {
     d.chi_edge.upload(m->chi_edge.data(), sizeof(uint32_t) * E);
     d.chi_w.upload(cw.data(), sizeof(double) * E);
     d.trans_lin.upload(tlin.data(), sizeof(double) * E);
+    // packed per-node records of the frontier kernels (CSR order kept)
+    std::vector<FwdAdj> fadj(N);
+    std::vector<BwdAdj> badj(N);
+    for (uint32_t v = 0; v < N; v++) {
+        FwdAdj f{};
+        BwdAdj b{};
+        const uint32_t np = m->par_off[v + 1] - m->par_off[v], nc = m->chi_off[v + 1] - m->chi_off[v];
+        f.over = b.over = (np > (uint32_t)ADJ_DEG || nc > (uint32_t)ADJ_DEG) ? 1 : 0;
+        f.npar = (uint8_t)std::min<uint32_t>(np, ADJ_DEG);
+        f.nchi = b.nchi = (uint8_t)std::min<uint32_t>(nc, ADJ_DEG);
+        f.emis = b.emis = m->emission[v];
+        f.init = ilin[v];
+        for (uint32_t q = 0; q < (uint32_t)ADJ_DEG; q++) {
+            f.par[q] = f.chi[q] = b.chi[q] = 0xffffffffu;
+            if (q < f.npar) {
+                f.par[q] = m->par_node[m->par_off[v] + q];
+                f.par_w[q] = pw[m->par_off[v] + q];
+            }
+            if (q < f.nchi) {
+                const uint32_t u = m->chi_node[m->chi_off[v] + q];
+                f.chi[q] = b.chi[q] = u;
+                b.chi_w[q] = cw[m->chi_off[v] + q];
+                b.chi_emis[q] = m->emission[u];
+            }
+        }
+        fadj[v] = f;
+        badj[v] = b;
+    }
+    d.fadj.upload(fadj.data(), sizeof(FwdAdj) * N);
+    d.badj.upload(badj.data(), sizeof(BwdAdj) * N);
     d.max_degree = 0;
     for (uint32_t v = 0; v < N; v++)
         d.max_degree = std::max(d.max_degree, std::max(m->par_off[v + 1] - m->par_off[v], m->chi_off[v + 1] - m->chi_off[v]));

@@ -114,6 +114,29 @@ struct NodeRec {
 static constexpr uint32_t CHAIN_F = 1u, CHAIN_B = 2u;
 static constexpr int CHAIN_HOPS = 6;
 
+// Everything the sparse (frontier) kernels need to know about one node, in ONE aligned record: a
+// wave that meets a new node pays one memory round trip for it instead of the CSR's three dependent
+// ones (offsets -> neighbour ids / weights -> their emissions).  Neighbours keep the CSR (petgraph)
+// order.  MultiDbg bounds the degree by 5 (multi_dbg.rs:82); `over` marks nodes beyond that, which
+// only the dense kernels support.
+static constexpr int ADJ_DEG = 5;
+struct alignas(16) FwdAdj {   // forward: expansion to children, sums over parents
+    double par_w[ADJ_DEG];    // linear transition probability parent -> this node (the model's own)
+    double init;
+    uint32_t par[ADJ_DEG];
+    uint32_t chi[ADJ_DEG];
+    uint8_t emis, npar, nchi, over;
+    uint32_t pad;
+};
+struct alignas(16) BwdAdj {   // backward: sums over children
+    double chi_w[ADJ_DEG];
+    uint32_t chi[ADJ_DEG];
+    uint8_t chi_emis[ADJ_DEG];
+    uint8_t emis, nchi, over;
+    uint32_t pad;
+};
+static_assert(sizeof(FwdAdj) == 96 && sizeof(BwdAdj) == 80, "adjacency record layout");
+
 struct ModelDev {
     uint32_t N = 0, E = 0;
     DevBuf nodes;            // NodeRec[N]
@@ -127,6 +150,7 @@ struct ModelDev {
     DevBuf chi_off, chi_node, chi_w;
     DevBuf par_edge, chi_edge;        // u32[E] edge ids (candidate batches index trans by edge)
     DevBuf trans_lin;                 // f64[E] by edge id
+    DevBuf fadj, badj;                // FwdAdj[N], BwdAdj[N]
     DevBuf logib;                     // f64[logib_len] forward InsBegin chain (log)
     size_t logib_len = 0;
     uint32_t max_degree = 0;

@@ -121,6 +121,8 @@ struct SparseModel {
     const uint32_t *chi_off, *chi_node, *chi_edge;
     const double *trans;  // [E] by edge id (per candidate: offset applied by the caller)
     const double *par_w, *chi_w;  // [E] linear trans prob aligned with par_node / chi_node (the model's own)
+    const FwdAdj *fadj;           // [N] packed per-node records (the model's own init / trans)
+    const BwdAdj *badj;
     LinParams lp;
     const double *logib;  // forward InsBegin chain (log), [>= max read length]
 };

@@ -94,6 +94,8 @@ inline SparseModel sparse_model_of(const phmm_model *m) {
     s.chi_node = d.chi_node.as<uint32_t>();
     s.chi_edge = d.chi_edge.as<uint32_t>();
     s.trans = d.trans_lin.as<double>();
+    s.fadj = d.fadj.as<FwdAdj>();
+    s.badj = d.badj.as<BwdAdj>();
     s.par_w = d.par_w.as<double>();
     s.chi_w = d.chi_w.as<double>();
     s.lp = m->lin;

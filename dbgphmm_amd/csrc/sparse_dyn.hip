@@ -381,7 +381,10 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     std::vector<std::unique_ptr<PlanCtx>> plans;
     int active = 0;
     std::exception_ptr first_error;
-    int n_workers = 3;
+    // Default: one worker.  Measured on cfg3 (MI355X): 3 workers cut the step from 514 to 465 ms, but the
+    // sparse waves that share the SIMDs with the dense kernels take bwd_step<64> from 4.0 to 2.9 TB/s;
+    // until the frontier kernels are cheaper the pipeline stays opt-in (PHMM_WORKERS=2..4).
+    int n_workers = 1;
     if (const char *e = std::getenv("PHMM_WORKERS")) n_workers = std::max(1, std::min(phmm_model::MAX_WORKERS, std::atoi(e)));
     int chunk_groups = 0;  // 0: automatic
     if (const char *e = std::getenv("PHMM_CHUNK_GROUPS")) chunk_groups = std::max(0, std::atoi(e));
@@ -531,13 +534,15 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         trace("staging+upload");
         // ---- dense warm-up with per-read switch decisions
         int pos = 0;
-        LaunchTimer lt(timing_enabled());
+        // per-launch statistics (bench.py's roofline) cover the full-width instantiation fwd_step<64> only
+        const bool st_on = W == 64;
+        LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock(dense_token);
         for (;; pos++) {
             lt.begin();
             launch_fwd_step(W, a, pos);  // column pos (if pos < Lc), d + totals maximum of column pos-1
             lt.end();
-            st.launches[0]++;
+            if (st_on) st.launches[0]++;
             HIP_CHECK(hipMemsetAsync(wa.undecided, 0, sizeof(int) * 2, s));
             hipLaunchKernelGGL(warm_decide_fused, dim3((lanes + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, s, wa, pos,
                                lanes, W);
@@ -589,7 +594,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 sparse_lanes.push_back((uint32_t)gi);
             }
         }
-        st.cells[0] += dense_cells;
+        if (st_on) st.cells[0] += dense_cells;
         DevBuf sel;
         if (!need400.empty()) {
             // forced switch at n_warmup with > 400 nodes inside the ratio: keep the 400 best

@@ -59,14 +59,19 @@ def main():
         "copy3x8": {"bytes_read": n3, "bytes_written": n3, "FETCH_SIZE_KB": mean_of(cf, "calib_copy3x8"),
                     "WRITE_SIZE_KB": mean_of(cw, "calib_copy3x8")},
     }
-    fetch_corr = n3 / (calib["copy3x8"]["FETCH_SIZE_KB"] * KB)
-    write_corr = n3 / (calib["copy3x8"]["WRITE_SIZE_KB"] * KB)
-    calib["fetch_bytes_per_counted_byte"] = fetch_corr
-    calib["write_bytes_per_counted_byte"] = write_corr
     calib["read8_factor"] = a.calib_bytes / (calib["read8"]["FETCH_SIZE_KB"] * KB)
     calib["read16_factor"] = a.calib_bytes / (calib["read16"]["FETCH_SIZE_KB"] * KB)
     calib["write8_factor"] = a.calib_bytes / (calib["write8"]["WRITE_SIZE_KB"] * KB)
     calib["write16_factor"] = a.calib_bytes / (calib["write16"]["WRITE_SIZE_KB"] * KB)
+    # the dense kernels move one f64 per lane per access: the single-stream 8 B/lane factors apply.
+    # copy3x8 (three such streams in, three out, interleaved) is the cross-check: with these factors it
+    # reads back as copy3x8_fetch_ratio / copy3x8_write_ratio x its true byte count.
+    fetch_corr = calib["read8_factor"]
+    write_corr = calib["write8_factor"]
+    calib["fetch_bytes_per_counted_byte"] = fetch_corr
+    calib["write_bytes_per_counted_byte"] = write_corr
+    calib["copy3x8_fetch_ratio"] = calib["copy3x8"]["FETCH_SIZE_KB"] * KB * fetch_corr / n3
+    calib["copy3x8_write_ratio"] = calib["copy3x8"]["WRITE_SIZE_KB"] * KB * write_corr / n3
 
     bf, bw = load(a.bench_fetch, "FETCH_SIZE"), load(a.bench_write, "WRITE_SIZE")
     kernels = {}
@@ -84,8 +89,8 @@ def main():
         }
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (kernel-trace only), "
                      "bench.py --steps 1 --warmup 0 --no-cpu-baseline and tools/pmc_calib",
-           "correction": "bytes = counter[KB] * 1024 * factor, factor from calib_copy3x8 (three 8 B/lane streams in, "
-                         "three out: the dense kernels' pattern)",
+           "correction": "bytes = counter[KB] * 1024 * factor; factors from the 8 B/lane streaming kernels of "
+                         "tools/pmc_calib.hip (FETCH_SIZE x2, WRITE_SIZE x1 on gfx950)",
            "calibration": calib, "kernels": kernels}
     s = json.dumps(doc, indent=1)
     if a.out:

@@ -16,5 +16,5 @@ cd $REPO
 python3 tools/pmc_traffic.py --calib-fetch $OUT/calib_fetch --calib-write $OUT/calib_write --bench-fetch $OUT/bench_fetch --bench-write $OUT/bench_write --out $OUT/pmc_traffic.json
 # keep only the summaries (the raw traces are large)
 find $OUT -name '*kernel_trace.csv' -delete
-find $OUT/bench_fetch $OUT/bench_write -name '*counter_collection.csv' -delete
+find $OUT/bench_fetch $OUT/bench_write -name "*counter_collection.csv" -delete
 ls -R $OUT | head -50
