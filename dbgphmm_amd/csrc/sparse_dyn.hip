@@ -27,6 +27,7 @@
 #include "frontier_dev.h"
 #include "sparse_dyn.h"
 #include "sparse_fwd_kernel.h"
+#include "lean_fwd_kernel.h"
 
 namespace phmm {
 
@@ -677,16 +678,19 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 std::vector<uint32_t> herr(lanes);
                 std::vector<int> hstop(lanes);
                 bool pool_full = false;
+                const bool lean_ok = m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
                 for (int round = 0; round < 64 && !todo.empty() && !pool_full; round++) {
                     // round 0: A <400> from the dense column; then B <64> to the end, and for the reads
                     // it could not hold a short C <400> burst followed by B again
                     const int phase = round == 0 ? 0 : ((round & 1) ? 1 : 2);
                     HIP_CHECK(hipMemcpyAsync(wp + o_lanes, todo.data(), todo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
                     fa.mode = phase == 0 ? 0 : 1;
-                    fa.max_steps = phase == 0 ? 6 : (phase == 2 ? 8 : 0);
-                    // B class: 128 slots while every read still gets a wave slot (8 waves/CU), else 64 (16/CU)
-                    if (phase == 1 && todo.size() > 2048)
-                        hipLaunchKernelGGL((sparse_forward_kernel<64>), dim3((unsigned)todo.size()), dim3(64), 0, s, fa);
+                    // C bursts grow (8, 16, ... 512 positions) so that a read whose frontier stays wide still ends
+                    fa.max_steps = phase == 0 ? 6 : (phase == 2 ? (8 << std::min(round / 2 - 1, 6)) : 0);
+                    // B class: one lane per node (lean_fwd_kernel.h); graphs beyond its degree bound use the
+                    // generic 128-slot vector kernel
+                    if (phase == 1 && lean_ok)
+                        hipLaunchKernelGGL(lean_forward_kernel, dim3((unsigned)todo.size()), dim3(64), 0, s, fa);
                     else if (phase == 1)
                         hipLaunchKernelGGL((sparse_forward_kernel<128>), dim3((unsigned)todo.size()), dim3(64), 0, s, fa);
                     else
