@@ -21,39 +21,10 @@
 // host continues in the 400-slot class, exactly like the generic <64> kernel.
 #pragma once
 
+#include "lean_common.h"
 #include "sparse_fwd_kernel.h"
 
 namespace phmm {
-
-static constexpr uint32_t LN_EMPTY = 0xffffffffu;
-static constexpr int LN_HASH = 256;
-static constexpr uint64_t LN_SLAB = 32768;  // record-pool bytes claimed per atomic
-
-struct LeanShared {
-    uint32_t hkey[LN_HASH];
-    uint8_t hval[LN_HASH];
-    uint32_t winkey[64];
-    uint16_t winh[64];
-    unsigned long long mark;
-};
-
-__device__ __forceinline__ uint32_t ln_hash(uint32_t id) { return (id * 2654435761u) >> 24; }
-
-// lane of node `id` or -1
-__device__ __forceinline__ int ln_find(const LeanShared &sh, uint32_t id) {
-    uint32_t h = ln_hash(id);
-    for (;;) {
-        const uint32_t k = sh.hkey[h];
-        if (k == id) return (int)sh.hval[h];
-        if (k == LN_EMPTY) return -1;
-        h = (h + 1) & (LN_HASH - 1);
-    }
-}
-
-__device__ __forceinline__ double ln_shfl(double v, int src) {
-    // value of lane `src` (any lane when src < 0: the caller masks the result)
-    return __shfl(v, src < 0 ? 0 : src);
-}
 
 struct LeanLane {
     uint32_t id;          // node on this lane (LN_EMPTY: free)
@@ -199,18 +170,7 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
         const uint8_t x = xn;
         if (pos + 1 < end) xn = a.bases[((size_t)g * a.Lb + pos + 1) * a.W + r];
         // ---- node -> lane map of the resident nodes (previous column)
-        for (int h = lane; h < LN_HASH; h += 64) sh.hkey[h] = LN_EMPTY;
-        __syncthreads();
-        if (L.id != LN_EMPTY) {
-            uint32_t h = ln_hash(L.id);
-            for (;;) {
-                const uint32_t old = atomicCAS(&sh.hkey[h], LN_EMPTY, L.id);
-                if (old == LN_EMPTY) break;
-                h = (h + 1) & (LN_HASH - 1);
-            }
-            sh.hval[h] = (uint8_t)lane;
-        }
-        __syncthreads();
+        ln_rebuild(sh, L.id);
         // ---- top = previous nodes within the ratio of the best total (table.rs:134-149)
         const double t = L.id != LN_EMPTY ? L.pm + L.pi + L.pd : 0.0;
         const double tmax = wave_max(t);

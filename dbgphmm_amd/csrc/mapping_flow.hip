@@ -18,6 +18,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "sparse_dyn.h"
+#include "lean_bwd_kernel.h"
 
 namespace phmm {
 
@@ -101,42 +102,6 @@ __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32
     __syncthreads();
     return true;
 }
-
-// Capacity classes as in the forward kernel (sparse_fwd_kernel.h): the tail of a read is walked
-// by a <64>-slot kernel (many reads per CU), the few positions next to the dense/sparse switch
-// (forward records of up to 400 entries) by the <400>-slot kernel, which also hands the column
-// over to the dense backward kernel.  Between two phases the last B column travels through a
-// per-read hand-off slot in HBM.
-static constexpr int HANDOFF_CAP = 128;
-struct BHandoff {
-    int n, E;
-    uint32_t id[HANDOFF_CAP];
-    double m[HANDOFF_CAP], i[HANDOFF_CAP], d[HANDOFF_CAP];
-};
-
-struct SparseBwdArgs {
-    SparseModel M;
-    DenseArgs d;
-    int W, Lb;
-    const int *sw;
-    const uint8_t *bases;
-    RecPool fpool, mpool;
-    const uint64_t *lane_pos0;  // forward-record position base of each lane (chunk local)
-    const uint64_t *map_pos0;   // global read position base of each lane (mapping records)
-    const uint32_t *lanes;
-    double ratio_lin;
-    uint32_t *err;
-    // list mode (backward_with_mapping, backward.rs:59-93): B.tables[i] over mapping.nodes(i); no dense head
-    const uint64_t *list_off;   // [total_pos+1] (global positions) or null
-    const uint32_t *list_nodes;
-    int topk;        // > 0: to_mapping(topk) instead of to_mapping_by_score_ratio
-    int mode;        // 0: start at the last position from b_init; 1: resume from the hand-off slot
-    int *stop;       // [lanes] in (mode 1): position to compute next; out: see below
-    BHandoff *hand;  // [lanes]
-};
-// stop[gi] on exit: s0      -> finished (column s0+1 handed to the dense kernel)
-//                   len     -> nothing done (the record of the last position does not fit the class)
-//                   other p -> positions > p are done, B.tables[p+1] is in the hand-off slot
 
 template <int CAP>
 __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs a) {
@@ -579,11 +544,14 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             std::vector<uint32_t> todo = sparse_lanes;
             std::vector<int> hstop(lanes);
             std::vector<uint32_t> herr2(lanes);
+            const bool lean_ok = m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
             for (int round = 0; round < 64 && !todo.empty(); round++) {
                 const bool small = (round & 1) == 0;
                 HIP_CHECK(hipMemcpyAsync(cp + o_lanes, todo.data(), sizeof(uint32_t) * todo.size(), hipMemcpyHostToDevice, s));
                 ba.mode = round == 0 ? 0 : 1;
-                if (small)
+                if (small && lean_ok)
+                    hipLaunchKernelGGL(lean_backward_kernel, dim3((unsigned)todo.size()), dim3(64), 0, s, ba);
+                else if (small)
                     hipLaunchKernelGGL((sparse_backward_kernel<64>), dim3((unsigned)todo.size()), dim3(64), 0, s, ba);
                 else
                     hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)todo.size()), dim3(64), 0, s, ba);
@@ -733,7 +701,8 @@ static void init_sink(phmm_model *m, const phmm_reads *reads, MappingSink &sink)
     const uint64_t n_pos = reads->total;
     sink.reads = reads;
     sink.total_pos = n_pos;
-    sink.cap = std::max<uint64_t>(m->wset().aux[5].bytes, n_pos * 160 + (1u << 20));
+    // (+ 2 x 64 KB per read: the frontier kernels claim the pool in 32 KB slabs per wave)
+    sink.cap = std::max<uint64_t>(m->wset().aux[5].bytes, n_pos * 160 + reads->R * 131072 + (1u << 20));
     m->wset().aux[5].reserve(sink.cap);
     m->wset().aux[6].reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1));
     HIP_CHECK(hipMemsetAsync(m->wset().aux[6].p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1), s));

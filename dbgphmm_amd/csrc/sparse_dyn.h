@@ -109,6 +109,44 @@ inline SparseModel sparse_model_of(const phmm_model *m) {
 
 namespace phmm {
 
+// Capacity classes as in the forward kernel (sparse_fwd_kernel.h): the tail of a read is walked
+// by a <64>-slot kernel (many reads per CU), the few positions next to the dense/sparse switch
+// (forward records of up to 400 entries) by the <400>-slot kernel, which also hands the column
+// over to the dense backward kernel.  Between two phases the last B column travels through a
+// per-read hand-off slot in HBM.
+static constexpr int HANDOFF_CAP = 128;
+struct BHandoff {
+    int n, E;
+    uint32_t id[HANDOFF_CAP];
+    double m[HANDOFF_CAP], i[HANDOFF_CAP], d[HANDOFF_CAP];
+};
+
+struct SparseBwdArgs {
+    SparseModel M;
+    DenseArgs d;
+    int W, Lb;
+    const int *sw;
+    const uint8_t *bases;
+    RecPool fpool, mpool;
+    const uint64_t *lane_pos0;  // forward-record position base of each lane (chunk local)
+    const uint64_t *map_pos0;   // global read position base of each lane (mapping records)
+    const uint32_t *lanes;
+    double ratio_lin;
+    uint32_t *err;
+    // list mode (backward_with_mapping, backward.rs:59-93): B.tables[i] over mapping.nodes(i); no dense head
+    const uint64_t *list_off;   // [total_pos+1] (global positions) or null
+    const uint32_t *list_nodes;
+    int topk;        // > 0: to_mapping(topk) instead of to_mapping_by_score_ratio
+    int mode;        // 0: start at the last position from b_init; 1: resume from the hand-off slot
+    int *stop;       // [lanes] in (mode 1): position to compute next; out: see below
+    BHandoff *hand;  // [lanes]
+};
+// stop[gi] on exit: s0      -> finished (column s0+1 handed to the dense kernel)
+//                   len     -> nothing done (the record of the last position does not fit the class)
+//                   other p -> positions > p are done, B.tables[p+1] is in the hand-off slot
+
+
+
 // Device-side collector of the mapping lists of all reads: one record pool for the whole call,
 // record offsets indexed by the GLOBAL read position (reads->off[read] + i), so the final CSR is
 // produced on the device (counts -> scan -> compaction) without a host pass over positions.
