@@ -202,6 +202,20 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
             L.m = pe * (acc + L.r.init * c_begin);
             L.i = lp.p_random * (lp.p_MI * L.pm + lp.p_II * L.pi + lp.p_DI * L.pd);
         }
+        // The previous column's values are not needed any more.  When lanes are short, the previous-only
+        // nodes leave now instead of at the end of the step (one that comes back as a Del-level node is
+        // fetched again), so that a wide frontier still fits the 64 lanes.
+        {
+            const unsigned long long resident = __ballot(L.id != LN_EMPTY);
+            if (64 - __popcll(resident) < 16 && (resident & ~act) != 0ull) {
+                if (!is_act) {
+                    L.id = LN_EMPTY;
+                    L.pm = L.pi = L.pd = 0.0;
+                }
+                ln_rebuild(sh, L.id);
+                ln_links(sh, L);
+            }
+        }
         // ---- adaptive fd (forward.rs:423-524)
         unsigned long long members = act, srcm = act;
         double lv = lp.p_MD * L.m + lp.p_ID * L.i;  // level value handed to the next level

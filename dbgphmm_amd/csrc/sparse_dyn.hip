@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <deque>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -379,6 +380,13 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     std::mutex dense_token;
     std::condition_variable cv;
     std::deque<Item> queue;
+    // Plans of deferred reads (a handful of reads, latency-bound from end to end) run on a side worker
+    // with its own stream while the calling thread goes on with the next chunk of the main plan.
+    std::deque<Item> side_queue;
+    std::thread side_thread;
+    bool side_started = false, main_done = false, single_mode = false;
+    CallStats side_stats;
+    const bool side_on = std::getenv("PHMM_NO_SIDE_WORKER") == nullptr;
     std::vector<std::unique_ptr<PlanCtx>> plans;
     int active = 0;
     std::exception_ptr first_error;
@@ -392,7 +400,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     const uint64_t limit_total = table_budget(m->owned_table_bytes());
 
     // cut a plan into items (caller holds `mu` or is the only thread)
-    auto enqueue_plan = [&](std::unique_ptr<PlanCtx> pcu) {
+    auto enqueue_plan = [&](std::unique_ptr<PlanCtx> pcu, std::deque<Item> &dst) {
         PlanCtx *pc = pcu.get();
         const Plan &plan = pc->plan;
         const int W = plan.W;
@@ -412,12 +420,13 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8;
             int ngc = (int)std::min<uint64_t>(plan.ng_total - g0, std::max<uint64_t>(1, limit / std::max<size_t>(per_group, 1)));
             ngc = std::min(ngc, std::max(1, target));
-            queue.push_back(Item{pc, g0, ngc, Lc, Lfull});
+            dst.push_back(Item{pc, g0, ngc, Lc, Lfull});
             g0 += ngc;
         }
         plans.push_back(std::move(pcu));
     };
 
+    std::function<void()> start_side_worker;
     auto run_chunk = [&](const Item &it) {
         hipStream_t s = current_stream();
         CallStats &st = stats();
@@ -538,7 +547,8 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         // per-launch statistics (bench.py's roofline) cover the full-width instantiation fwd_step<64> only
         const bool st_on = W == 64;
         LaunchTimer lt(timing_enabled() && st_on);
-        std::unique_lock<std::mutex> dense_lock(dense_token);
+        std::unique_lock<std::mutex> dense_lock(dense_token, std::defer_lock);
+        if (W >= 32) dense_lock.lock();  // narrow plans (deferred reads) do not load the memory system
         for (;; pos++) {
             lt.begin();
             launch_fwd_step(W, a, pos);  // column pos (if pos < Lc), d + totals maximum of column pos-1
@@ -562,7 +572,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             if (pos >= Lc) PHMM_THROW(PHMM_EINTERNAL, "warm-up did not terminate");
         }
         st.ms[0] += lt.total_ms();
-        dense_lock.unlock();
+        if (dense_lock.owns_lock()) dense_lock.unlock();
         trace("dense warm-up");
         // reads that ended inside the warm-up: fe of their last (dense) column
         launch_fwd_finish(W, a);
@@ -742,7 +752,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 mc.d_logp_sparse = fa.out_logp;
                 mc.cand_node = wa.cand_node;
                 mc.cand_tot = wa.cand_tot;
-                mc.dense_token = &dense_token;
+                mc.dense_token = W >= 32 ? &dense_token : nullptr;
                 trace("sparse forward");
                 mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
                 trace("mapping backward total");
@@ -770,7 +780,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             mc.d_logp_sparse = (double *)(wp + o_out);
             mc.cand_node = wa.cand_node;
             mc.cand_tot = wa.cand_tot;
-                mc.dense_token = &dense_token;
+                mc.dense_token = W >= 32 ? &dense_token : nullptr;
             mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
         }
         for (int gi = 0; gi < lanes; gi++) {
@@ -783,10 +793,45 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         if (!deferred_ids.empty()) {
             std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan_ids(m, reads, deferred_ids), (int64_t)prm.n_warmup + 2, false, {}});
             std::lock_guard<std::mutex> lk(mu);
-            enqueue_plan(std::move(pc));
+            if (single_mode && side_on) {
+                enqueue_plan(std::move(pc), side_queue);
+                if (!side_started) {
+                    side_started = true;
+                    start_side_worker();
+                }
+            } else {
+                enqueue_plan(std::move(pc), queue);
+            }
             cv.notify_all();
         }
     };  // run_chunk
+    start_side_worker = [&]() {
+        const ThreadContext ctx = capture_thread_context();
+        if (!m->wstream[1]) HIP_CHECK(hipStreamCreateWithFlags(&m->wstream[1], hipStreamNonBlocking));
+        side_thread = std::thread([&, ctx]() {
+            adopt_thread_context(ctx, m->wstream[1], 1);
+            for (;;) {
+                Item it{};
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !side_queue.empty() || main_done || first_error; });
+                    if (first_error) break;
+                    if (side_queue.empty()) break;  // main_done
+                    it = side_queue.front();
+                    side_queue.pop_front();
+                }
+                try {
+                    run_chunk(it);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!first_error) first_error = std::current_exception();
+                }
+            }
+            (void)hipStreamSynchronize(m->wstream[1]);
+            std::lock_guard<std::mutex> lk(mu);
+            side_stats = stats();
+        });
+    };
 
     auto worker_loop = [&]() {
         for (;;) {
@@ -819,11 +864,26 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         int min_groups = 8;
         if (const char *e = std::getenv("PHMM_PIPELINE_MIN_GROUPS")) min_groups = std::max(1, std::atoi(e));
         if (pc->plan.ng_total < min_groups) n_workers = 1;
-        enqueue_plan(std::move(pc));
+        enqueue_plan(std::move(pc), queue);
     }
     const int n_threads = (int)std::min<size_t>((size_t)n_workers, queue.size());
     if (n_threads <= 1) {
+        single_mode = true;
         worker_loop();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            main_done = true;
+        }
+        cv.notify_all();
+        if (side_started) {
+            side_thread.join();
+            CallStats &st = stats();
+            for (int k = 0; k < 4; k++) {
+                st.ms[k] += side_stats.ms[k];
+                st.launches[k] += side_stats.launches[k];
+                st.cells[k] += side_stats.cells[k];
+            }
+        }
     } else {
         HIP_CHECK(hipStreamSynchronize(current_stream()));  // uploads / memsets the chunks depend on
         const ThreadContext ctx = capture_thread_context();
