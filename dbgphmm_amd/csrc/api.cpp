@@ -317,6 +317,16 @@ int phmm_run_dense(phmm_model *m, const phmm_reads *reads, double *lf, double *l
     });
 }
 
+int phmm_run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_ef, double *out_if) {
+    return guarded([&] {
+        if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
+        if (reads->R == 0) return;
+        for (uint64_t r = 0; r < reads->R; r++)
+            if (reads->off[r + 1] == reads->off[r]) PHMM_THROW(PHMM_EINVAL, "empty read (reference panics: table.rs:388)");
+        run_dense_edges(m, reads, out_lf, out_ef, out_if);
+    });
+}
+
 int phmm_dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i, double *f_d,
                       double *f_scal, double *b_m, double *b_i, double *b_d, double *b_scal) {
     return guarded([&] {
@@ -436,6 +446,19 @@ int phmm_full_prob_reads_candidates(phmm_model *m, const phmm_reads *reads, cons
         if (!init_logp || (m->E && !trans_logp)) PHMM_THROW(PHMM_EINVAL, "NULL candidate arrays");
         check_mapping_nodes(m, mp, reads);
         full_prob_reads_hinted(m, reads, mp, n_cand, init_logp, trans_logp, out_logp, out_total);
+    });
+}
+
+int phmm_full_prob_reads_copy_nums(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
+                                   const uint32_t *copy_nums, uint32_t min_copy_num, double *out_logp,
+                                   double *out_total) {
+    return guarded([&] {
+        if (!m || !reads || !mp) PHMM_THROW(PHMM_EINVAL, "NULL model, reads or mappings");
+        if (n_cand == 0) return;
+        if (!copy_nums) PHMM_THROW(PHMM_EINVAL, "NULL copy numbers");
+        check_mapping_nodes(m, mp, reads);
+        full_prob_reads_hinted(m, reads, mp, n_cand, nullptr, nullptr, out_logp, out_total, nullptr, copy_nums,
+                               min_copy_num);
     });
 }
 

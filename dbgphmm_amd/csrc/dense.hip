@@ -589,6 +589,85 @@ __global__ void __launch_bounds__(BLOCK) freq_reduce(const double *accg, int ng,
 }
 
 // debug: scaled linear table -> natural-log table in the caller's [L][N] layout (W == 1)
+// Transition posteriors summed over the positions of every read (PHMMOutput::to_edge_and_init_freqs,
+// freq.rs:276-298 over to_trans_and_init_probs, freq.rs:332-389), from the FULL forward and backward
+// tables of the chunk.  For edge e = (k -> l) and merged index i = 1..len (F.table_merged(i) = column i-1):
+//   to Match (i < len):  t_e e_l(x[i]) B[i+1].m[l] (p_MM F.m[k] + p_IM F.i[k] + p_DM F.d[k]) / P
+//   to Del:              t_e           B[i].d[l]   (p_MD F.m[k] + p_ID F.i[k] + p_DD F.d[k]) / P
+// (B[len] = b_init: m = d = p_end); the Begin state gives the per-node init frequencies
+//   i = 0: init_v (p_MM e_v(x[0]) B[1].m[v] + p_MD B[0].d[v]) / P        (mb = 1, forward.rs:255-266)
+//   i >= 1: ib_{i-1} init_v (p_IM e_v(x[i]) B[i+1].m[v] + p_ID B[i].d[v]) / P
+// One row of W lanes per edge (blockIdx.x: edges, then nodes for the init part), lanes = reads.
+template <int W>
+__global__ void __launch_bounds__(BLOCK) edge_freq_kernel(const DenseArgs a, const uint32_t *esrc, const uint32_t *edst,
+                                                          const double *trans, const double *init, int E, double *accE,
+                                                          double *accI) {
+    constexpr int ROWS = BLOCK / W;
+    const int g = blockIdx.y;
+    const int r = threadIdx.x % W, row = threadIdx.x / W;
+    const int item = blockIdx.x * ROWS + row;  // < E: edge; else node item - E
+    if (item >= E + a.N) return;
+    const bool is_edge = item < E;
+    const int k = is_edge ? (int)esrc[item] : 0;
+    const int l = is_edge ? (int)edst[item] : item - E;
+    const double t = is_edge ? trans[item] : init[l];
+    const int len = a.len[g * W + r];
+    const LinParams &lp = a.lp;
+    const size_t NW = (size_t)a.N * W;
+    const double lpf = a.logPf[g * W + r];
+    const uint8_t el = a.emis[l];
+    double acc = 0.0;
+    if (len > 0 && lpf > -INFINITY && t != 0.0) {
+        const int *FE = a.FE + (size_t)g * (a.Lc + 1) * W + r;
+        const int *BE = a.BE + (size_t)g * (a.Lc + 1) * W + r;
+        for (int i = is_edge ? 1 : 0; i <= len; i++) {
+            // source side: F.table_merged(i)
+            double sm, sd;  // coefficients of the "to Match" and "to Del" terms, in units of 2^fe
+            int fe = 0;
+            if (is_edge) {
+                const size_t ix = ((size_t)g * a.Lc + (i - 1)) * NW + (size_t)k * W + r;
+                const double fm = a.Fm[ix], fi = a.Fi[ix], fd = a.Fd[ix];
+                sm = lp.p_MM * fm + lp.p_IM * fi + lp.p_DM * fd;
+                sd = lp.p_MD * fm + lp.p_ID * fi + lp.p_DD * fd;
+                fe = FE[(size_t)(i - 1) * W];
+            } else if (i == 0) {
+                sm = lp.p_MM;
+                sd = lp.p_MD;
+            } else {
+                const double ib = exp(a.logib[i - 1]);
+                sm = lp.p_IM * ib;
+                sd = lp.p_ID * ib;
+            }
+            // target side
+            double term = 0.0;
+            if (i < len) {
+                const uint8_t x = a.bases[((size_t)g * a.Lc + i) * W + r];
+                const double pe = el == x ? lp.p_match : lp.p_mismatch;
+                double bm;
+                int be;
+                if (i + 1 < len) {
+                    bm = a.Bm[((size_t)g * a.bcols + (i + 1)) * NW + (size_t)l * W + r];
+                    be = BE[(size_t)(i + 1) * W];
+                } else {
+                    bm = lp.p_end;
+                    be = 0;
+                }
+                term += sm * pe * bm * exp((double)(fe + be) * LN2 - lpf);
+                const double bd = a.Bd[((size_t)g * a.bcols + i) * NW + (size_t)l * W + r];
+                term += sd * bd * exp((double)(fe + BE[(size_t)i * W]) * LN2 - lpf);
+            } else {
+                term += sd * lp.p_end * exp((double)fe * LN2 - lpf);
+            }
+            acc += t * term;
+        }
+    }
+    const double tot = lanes_sum<W>(acc);
+    if (r == 0) {
+        if (is_edge) accE[(size_t)g * E + item] = tot;
+        else accI[(size_t)g * a.N + l] = tot;
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK) to_log_tables(const double *T, const int *E, int Lc, int N, int L,
                                                        double *out) {
     const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -817,9 +896,32 @@ void host_logib(const phmm_model *m, size_t n, std::vector<double> &out) {
     }
 }
 
+template <int W>
+static void launch_edge_freq_w(const DenseArgs &a, const uint32_t *esrc, const uint32_t *edst, const double *trans,
+                               const double *init, int E, double *accE, double *accI) {
+    constexpr int ROWS = BLOCK / W;
+    const unsigned nb = (unsigned)((E + a.N + ROWS - 1) / ROWS);
+    hipLaunchKernelGGL(edge_freq_kernel<W>, dim3(nb, a.ng), dim3(BLOCK), 0, current_stream(), a, esrc, edst, trans, init, E,
+                       accE, accI);
+}
+static void launch_edge_freq(int W, const DenseArgs &a, const uint32_t *esrc, const uint32_t *edst, const double *trans,
+                             const double *init, int E, double *accE, double *accI) {
+    switch (W) {
+    case 1: launch_edge_freq_w<1>(a, esrc, edst, trans, init, E, accE, accI); break;
+    case 2: launch_edge_freq_w<2>(a, esrc, edst, trans, init, E, accE, accI); break;
+    case 4: launch_edge_freq_w<4>(a, esrc, edst, trans, init, E, accE, accI); break;
+    case 8: launch_edge_freq_w<8>(a, esrc, edst, trans, init, E, accE, accI); break;
+    case 16: launch_edge_freq_w<16>(a, esrc, edst, trans, init, E, accE, accI); break;
+    case 32: launch_edge_freq_w<32>(a, esrc, edst, trans, init, E, accE, accI); break;
+    case 64: launch_edge_freq_w<64>(a, esrc, edst, trans, init, E, accE, accI); break;
+    default: PHMM_THROW(PHMM_EINTERNAL, "bad read-group width");
+    }
+}
+
 void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, uint64_t R,
                     const Plan &plan, bool full_b, bool eall, bool want_b, bool want_freq,
-                    double *out_lf, double *out_lb, double *out_nf, DenseArgs *dbg_args) {
+                    double *out_lf, double *out_lb, double *out_nf, DenseArgs *dbg_args, double *out_ef,
+                    double *out_if) {
     hipStream_t s = current_stream();
     CallStats &st = stats();
     st = CallStats();
@@ -843,6 +945,19 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
         HIP_CHECK(hipMemsetAsync(nf_dev.p, 0, sizeof(double) * m->N, s));
     }
 
+    const bool want_edge = out_ef || out_if;
+    DevBuf ef_dev, if_dev, accE, accI;
+    if (want_edge) {
+        ef_dev.reserve(sizeof(double) * std::max<uint32_t>(m->E, 1));
+        if_dev.reserve(sizeof(double) * m->N);
+        HIP_CHECK(hipMemsetAsync(ef_dev.p, 0, ef_dev.bytes, s));
+        HIP_CHECK(hipMemsetAsync(if_dev.p, 0, if_dev.bytes, s));
+    }
+    DevBuf d_esrc, d_edst;
+    if (want_edge && m->E) {
+        d_esrc.upload(m->esrc.data(), sizeof(uint32_t) * m->E);
+        d_edst.upload(m->edst.data(), sizeof(uint32_t) * m->E);
+    }
     int g0 = 0;
     bool first_chunk = true;
     while (g0 < plan.ng_total) {
@@ -890,6 +1005,19 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
         if (want_freq)
             hipLaunchKernelGGL(freq_reduce, dim3((m->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, a.accg, ngc,
                                (int)m->N, nf_dev.as<double>(), first_chunk ? 0 : 1);
+        if (want_edge) {
+            const int E = (int)m->E;
+            accE.reserve(sizeof(double) * (size_t)ngc * std::max(E, 1));
+            accI.reserve(sizeof(double) * (size_t)ngc * m->N);
+            launch_edge_freq(W, a, d_esrc.as<uint32_t>(), d_edst.as<uint32_t>(), m->dev.trans_lin.as<double>(),
+                             m->dev.init.as<double>(), E, accE.as<double>(), accI.as<double>());
+            if (E)
+                hipLaunchKernelGGL(freq_reduce, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, accE.as<double>(), ngc, E,
+                                   ef_dev.as<double>(), first_chunk ? 0 : 1);
+            hipLaunchKernelGGL(freq_reduce, dim3((m->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, accI.as<double>(), ngc,
+                               (int)m->N, if_dev.as<double>(), first_chunk ? 0 : 1);
+            HIP_CHECK(hipGetLastError());
+        }
         // per-read totals back to caller order
         std::vector<double> tlf((size_t)ngc * W), tlb;
         HIP_CHECK(hipMemcpyAsync(tlf.data(), a.logPf, tlf.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -926,12 +1054,21 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
     put(out_lf, lf);
     if (want_b) put(out_lb, lb);
     if (want_freq && out_nf) copy_out(out_nf, nf_dev.p, sizeof(double) * m->N);
+    if (out_ef && m->E) copy_out(out_ef, ef_dev.p, sizeof(double) * m->E);
+    if (out_if) copy_out(out_if, if_dev.p, sizeof(double) * m->N);
+}
+
+// PHMMOutput::to_edge_and_init_freqs summed over the reads (freq.rs:276-298): needs the full backward tables
+void run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_ef, double *out_if) {
+    Plan plan = make_plan(m, reads, 0);
+    run_dense_impl(m, reads->bases.data(), reads->off.data(), reads->R, plan, true, false, true, false, out_lf, nullptr,
+                   nullptr, nullptr, out_ef, out_if);
 }
 
 void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb, double *out_nf) {
     Plan plan = make_plan(m, reads, 0);
     run_dense_impl(m, reads->bases.data(), reads->off.data(), reads->R, plan, false, false, out_lb != nullptr,
-                   out_nf != nullptr, out_lf, out_lb, out_nf, nullptr);
+                   out_nf != nullptr, out_lf, out_lb, out_nf, nullptr, nullptr, nullptr);
 }
 
 void dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i, double *f_d,
@@ -948,7 +1085,7 @@ void dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m,
     DenseArgs a{};
     double lf = 0, lb = 0;
     run_dense_impl(m, one.bases.data(), one.off.data(), 1, plan, true, true, want_b, false, &lf, want_b ? &lb : nullptr,
-                   nullptr, &a);
+                   nullptr, &a, nullptr, nullptr);
     const int L = (int)len, N = (int)m->N;
     const size_t n = (size_t)L * N;
     DevBuf tmp;

@@ -268,11 +268,13 @@ void model_upload(phmm_model *m);        // closures + device arrays
 // dense driver (dense.hip)
 void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb,
                double *out_nf);
+void run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_ef, double *out_if);
 struct RecPool;
 // sparse / hinted drivers (sparse.hip)
 void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
                             const double *init_logp, const double *trans_logp, double *out_logp,
-                            double *out_total, const RecPool *pool = nullptr);
+                            double *out_total, const RecPool *pool = nullptr, const uint32_t *copy_nums = nullptr,
+                            uint32_t min_copy_num = 0);
 void upload_reads(const phmm_reads *r);
 void upload_mappings(const phmm_mappings *mp);
 void generate_mappings_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp_in, int use_max_ratio,

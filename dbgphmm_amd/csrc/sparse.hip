@@ -146,9 +146,46 @@ template <int CAP, int LPN> void launch_hinted(const HintedArgs &a, uint32_t n_r
 
 }  // namespace
 
+// Candidate (init, trans) vectors straight from copy-number vectors, in the linear domain
+// (SeqGraph::to_phmm_node / to_phmm_edge without edge copy numbers, seq_graph.rs:160-209, with
+// total_emittable_copy_num / total_emittable_child_copy_nums, seq_graph.rs:110-135):
+//   init[v]        = emittable(v) ? max(cn[v], min) / sum_{emittable u} max(cn[u], min) : 0
+//   trans[v -> w]  = emittable(w) and T_v > 0 ? max(cn[w], min) / T_v : 0,
+//   T_v            = sum over the emittable children u of v of max(cn[u], min)
+// Copy numbers are integers: the sums are exact and order-independent.
+__global__ void __launch_bounds__(256) cn_totals(const uint32_t *cn, const uint8_t *emis, uint32_t N, uint32_t min_cn,
+                                                 unsigned long long *tot) {
+    const uint32_t c = blockIdx.y;
+    unsigned long long s = 0;
+    for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < N; v += gridDim.x * 256)
+        if (emis[v] != (uint8_t)'n') s += max(cn[(size_t)c * N + v], min_cn);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&tot[c], s);
+}
+__global__ void __launch_bounds__(256) cn_probs(const uint32_t *cn, const uint8_t *emis, const uint32_t *chi_off,
+                                                const uint32_t *chi_node, const uint32_t *chi_edge, uint32_t N, uint32_t E,
+                                                uint32_t min_cn, const unsigned long long *tot, double *init, double *trans) {
+    const uint32_t c = blockIdx.y;
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= N) return;
+    const uint32_t *cc = cn + (size_t)c * N;
+    const unsigned long long total = tot[c];
+    init[(size_t)c * N + v] = (emis[v] != (uint8_t)'n' && total > 0) ? (double)max(cc[v], min_cn) / (double)total : 0.0;
+    unsigned long long tv = 0;
+    for (uint32_t a = chi_off[v]; a < chi_off[v + 1]; a++) {
+        const uint32_t u = chi_node[a];
+        if (emis[u] != (uint8_t)'n') tv += max(cc[u], min_cn);
+    }
+    for (uint32_t a = chi_off[v]; a < chi_off[v + 1]; a++) {
+        const uint32_t u = chi_node[a];
+        const uint32_t k = max(cc[u], min_cn);
+        trans[(size_t)c * E + chi_edge[a]] = (emis[u] != (uint8_t)'n' && tv > 0 && k > 0) ? (double)k / (double)tv : 0.0;
+    }
+}
+
 void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
                             const double *init_logp, const double *trans_logp, double *out_logp,
-                            double *out_total, const RecPool *pool) {
+                            double *out_total, const RecPool *pool, const uint32_t *copy_nums, uint32_t min_copy_num) {
     hipStream_t s = current_stream();
     CallStats &st = stats();
     st = CallStats();
@@ -179,6 +216,25 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
                                cand_trans.as<double>(), ne);
         }
         HIP_CHECK(hipStreamSynchronize(s));
+        d_init = cand_init.as<double>();
+        d_trans = cand_trans.as<double>();
+    } else if (copy_nums) {
+        const size_t ni = (size_t)n_cand * N, ne = (size_t)n_cand * E;
+        staging.reserve(ni * sizeof(uint32_t) + 256 + n_cand * sizeof(unsigned long long));
+        cand_init.reserve(ni * sizeof(double));
+        cand_trans.reserve(std::max<size_t>(ne, 1) * sizeof(double));
+        uint32_t *d_cn = staging.as<uint32_t>();
+        unsigned long long *d_tot = (unsigned long long *)(staging.as<char>() + (ni * sizeof(uint32_t) + 255) / 256 * 256);
+        HIP_CHECK(hipMemcpyAsync(d_cn, copy_nums, ni * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemsetAsync(d_tot, 0, n_cand * sizeof(unsigned long long), s));
+        const unsigned nb = (unsigned)((N + 255) / 256);
+        hipLaunchKernelGGL(cn_totals, dim3(std::min(nb, 256u), n_cand), dim3(256), 0, s, d_cn, m->dev.emis.as<uint8_t>(), N,
+                           min_copy_num, d_tot);
+        hipLaunchKernelGGL(cn_probs, dim3(nb, n_cand), dim3(256), 0, s, d_cn, m->dev.emis.as<uint8_t>(),
+                           m->dev.chi_off.as<uint32_t>(), m->dev.chi_node.as<uint32_t>(), m->dev.chi_edge.as<uint32_t>(), N, E,
+                           min_copy_num, d_tot, cand_init.as<double>(), cand_trans.as<double>());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(s));  // the caller's copy_nums may go away
         d_init = cand_init.as<double>();
         d_trans = cand_trans.as<double>();
     }

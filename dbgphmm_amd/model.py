@@ -217,6 +217,26 @@ class PHMMModel:
                                                               _ptr(lp), _ptr(tot)))
         return tot, lp
 
+    def run_dense_edge_freqs(self, reads: ReadCollection):
+        """PHMMOutput::to_edge_and_init_freqs (freq.rs:276-298) summed over the reads
+        -> (per-read ln P, edge_freq[E], init_freq[N])."""
+        lf, ef, nf = np.empty(len(reads)), np.empty(max(self.n_edges, 1)), np.empty(self.n_nodes)
+        _ffi.check(_ffi.lib().phmm_run_dense_edges(self._h, reads._h, _ptr(lf), _ptr(ef), _ptr(nf)))
+        return lf, ef[:self.n_edges], nf
+
+    def to_full_prob_reads_copy_nums(self, reads: ReadCollection, mappings: Mappings, copy_nums: np.ndarray,
+                                     min_copy_num: int = 0):
+        """The same loop with candidates given as copy-number vectors [C,N] (what the sampler varies,
+        posterior.rs:483-515); init / trans are derived on the device as SeqGraph::to_phmm does
+        (seq_graph.rs:160-209)."""
+        cn = np.ascontiguousarray(copy_nums, dtype=np.uint32)
+        Cn = cn.shape[0]
+        lp = np.empty((Cn, len(reads)))
+        tot = np.empty(Cn)
+        _ffi.check(_ffi.lib().phmm_full_prob_reads_copy_nums(self._h, reads._h, mappings._h, Cn, _ptr(cn),
+                                                             int(min_copy_num), _ptr(lp), _ptr(tot)))
+        return tot, lp
+
     def generate_mappings(self, reads: ReadCollection, mappings: Optional[Mappings] = None,
                           use_max_ratio: bool = True, out_node_freq=None):
         """PHMMModel::generate_mappings (hint.rs:193-220) -> (Mappings, node_freq[N])."""

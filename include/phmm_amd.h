@@ -112,6 +112,14 @@ void phmm_reads_destroy(phmm_reads *r);
 int phmm_run_dense(phmm_model *m, const phmm_reads *reads, double *out_logp_forward,
                    double *out_logp_backward, double *out_node_freq);
 
+/* Transition posteriors: PHMMOutput::to_edge_and_init_freqs (freq.rs:276-298, 332-389) of a dense
+ * `run`, summed over the reads (EM-style uses / tests; not called by `infer`).
+ *   out_edge_freq[E] = sum over reads, positions and the six transition kinds (mm im dm md id dd) of
+ *                      P(edge used | read);  out_init_freq[N] = the same for Begin -> node (mm im md id).
+ * Any output may be NULL or a device pointer.  Keeps the full backward tables of a chunk in HBM. */
+int phmm_run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_logp_forward,
+                         double *out_edge_freq, double *out_init_freq);
+
 /* Dense tables of ONE read for parity tests / `inspect`-style tools:
  * PHMMModel::forward / backward (forward.rs:24-45; backward.rs:24-53).
  * f_m/f_i/f_d: [L][N] natural-log values of F.tables[i]; f_scal: [L][3] = mb, ib, e.
@@ -155,6 +163,19 @@ int phmm_full_prob_reads_candidates(phmm_model *m, const phmm_reads *reads,
                                     const phmm_mappings *mappings, uint32_t n_candidates,
                                     const double *init_logp, const double *trans_logp,
                                     double *out_logp, double *out_total);
+
+/* The same loop with the candidates given as COPY-NUMBER vectors (what the sampler actually
+ * varies: `dbg.set_copy_nums(copy_nums); dbg.to_phmm(param)`, posterior.rs:485-487, 253) instead of
+ * probability vectors: copy_nums [C][N] (host pointer; PHMM node v = DBG k-mer v), and init / trans
+ * are derived on the device as SeqGraph::to_phmm does (seq_graph.rs:110-135, 160-209, no edge copy
+ * numbers): init[v] = max(cn[v], min_copy_num) / sum over emittable nodes, trans[v->w] =
+ * max(cn[w], min_copy_num) / sum over the emittable children of v; 0 into / from a non-emittable
+ * node (emission 'n').  min_copy_num: 0 = to_phmm, 1 = to_non_zero_phmm (seq_graph.rs:263-273).
+ * Removes the per-candidate host rebuild and the C x (N + E) x 8-byte upload of the form above. */
+int phmm_full_prob_reads_copy_nums(phmm_model *m, const phmm_reads *reads,
+                                   const phmm_mappings *mappings, uint32_t n_candidates,
+                                   const uint32_t *copy_nums, uint32_t min_copy_num,
+                                   double *out_logp, double *out_total);
 
 /* PHMMModel::generate_mappings (hint.rs:193-220): run_with_mapping when `mappings`
  * is given else run_sparse_adaptive(use_max_ratio); then to_mapping_by_score_ratio /

@@ -146,3 +146,33 @@ def test_errors(gpu_lib):
     arrays.edge_dst[0] = 99
     with pytest.raises(D.PhmmError):
         D.PHMMModel(arrays)
+
+
+def test_edge_freq_kats(gpu_lib):
+    """freq.rs:517-609: transition posteriors on the 10-node linear mock."""
+    gm = D.PHMMModel(D.mock_linear().to_phmm(D.PHMMParams.zero_error()))
+    _, ef, _ = gm.run_dense_edge_freqs(D.ReadCollection([b"CGATC"]))
+    assert np.all(ef[[0, 1, 2, 7, 8]] < 1e-4) and np.all(ef[3:7] > 0.9999)
+    gm = D.PHMMModel(D.mock_linear().to_phmm(D.PHMMParams.default()))
+    _, ef, _ = gm.run_dense_edge_freqs(D.ReadCollection([b"ATTCGTCGT"]))
+    assert np.allclose(ef, 0.99, atol=0.01)
+
+
+@pytest.mark.parametrize("n_reads", [1, 5, 70])
+def test_edge_and_init_freqs_match_oracle(gpu_lib, oracle, n_reads):
+    """PHMMOutput::to_edge_and_init_freqs (freq.rs:276-298, 332-389) summed over the reads."""
+    arrays, _ = small_dbg_model(300, 12, 0.01, seed=5)
+    reads = D.sample_reads(arrays, 10 ** 9, 60, seed=n_reads, max_reads=n_reads)
+    reads = [r[: max(1, len(r) - (j * 7) % 31)] for j, r in enumerate(reads)]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    lf, ef, nf = gm.run_dense_edge_freqs(D.ReadCollection(reads))
+    oef, onf = np.zeros(arrays.n_edges), np.zeros(arrays.n_nodes)
+    for r in reads:
+        e1, n1 = om.run(r).to_edge_and_init_freqs()
+        oef += e1
+        onf += n1
+    assert np.max(np.abs(ef - oef)) < TOL_FREQ * max(1, n_reads)
+    assert np.max(np.abs(nf - onf)) < TOL_FREQ * max(1, n_reads)
+    # every read leaves the Begin states about once (the forward `e` and the backward b_init treat a
+    # trailing deletion differently, as for the node posteriors above)
+    assert abs(nf.sum() - len(reads)) < 0.01 * len(reads)

@@ -78,6 +78,37 @@ def test_candidate_batch(gpu_lib, oracle):
         assert np.all((np.isneginf(lp2) & np.isneginf(lp[2])) | (np.abs(lp2 - lp[2]) < 1e-12))
 
 
+def test_candidate_copy_numbers_on_device(gpu_lib, oracle):
+    """candidates as copy-number vectors: init / trans built on the device (seq_graph.rs:160-209) give the
+    same likelihoods as the host-built probability vectors, for to_phmm (min 0) and to_non_zero_phmm (min 1)."""
+    arrays, sg, reads, om, mp = _setup(oracle, n_reads=12, seed=5)
+    rng = np.random.default_rng(1)
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    gmp = D.Mappings.from_arrays(rc, *mp)
+    for min_cn in (0, 1):
+        cns, inits, transs = [], [], []
+        for c in range(4):
+            cn = sg.copy_num.copy()
+            flip = rng.integers(0, cn.shape[0], size=10)
+            cn[flip] = rng.integers(0, 4, size=10)
+            sg2 = D.SeqGraph(cn, sg.base, sg.edge_src, sg.edge_dst, None)
+            with np.errstate(divide="ignore"):
+                a2 = D.vectorised_to_phmm(sg2, arrays.param, min_cn)
+            cns.append(cn)
+            inits.append(a2.init_logp)
+            transs.append(a2.trans_logp)
+        t1, lp1 = gm.to_full_prob_reads_candidates(rc, gmp, np.stack(inits), np.stack(transs))
+        t2, lp2 = gm.to_full_prob_reads_copy_nums(rc, gmp, np.stack(cns), min_cn)
+        with np.errstate(invalid="ignore"):
+            assert np.all((np.isneginf(lp1) & np.isneginf(lp2)) | (np.abs(lp1 - lp2) < TOL_LOGP))
+        # and against the oracle on the host-built model of one candidate
+        ol = oracle.Model(D.vectorised_to_phmm(D.SeqGraph(cns[1], sg.base, sg.edge_src, sg.edge_dst, None),
+                                               arrays.param, min_cn)).full_prob_reads(reads, mp, True, n_threads=8)
+        with np.errstate(invalid="ignore"):
+            assert np.all((np.isneginf(ol) & np.isneginf(lp2[1])) | (np.abs(ol - lp2[1]) < TOL_LOGP))
+
+
 def test_long_lists_use_bigger_class(gpu_lib, oracle):
     """node lists longer than 64/128 entries run in the 128/400-slot kernels."""
     arrays, sg, reads, om, _ = _setup(oracle, genome_len=500, n_reads=3, seed=13, read_len=40)
