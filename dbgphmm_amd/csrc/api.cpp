@@ -429,10 +429,7 @@ int phmm_full_prob_reads(phmm_model *m, const phmm_reads *reads, const phmm_mapp
             check_mapping_nodes(m, mp, reads);
             full_prob_reads_hinted(m, reads, mp, 1, nullptr, nullptr, out_logp, out_total);
         } else {
-            if (!use_max_ratio)
-                PHMM_THROW(PHMM_EINVAL, "use_max_ratio = false (fixed top-k frontier) is not built on the GPU path yet; "
-                                        "the production callers always pass true (multi_dbg/posterior.rs:254)");
-            full_prob_reads_sparse(m, reads, out_logp, out_total, nullptr);
+            full_prob_reads_sparse(m, reads, out_logp, out_total, nullptr, use_max_ratio != 0);
         }
     });
 }
@@ -473,10 +470,7 @@ int phmm_generate_mappings(phmm_model *m, const phmm_reads *reads, const phmm_ma
             generate_mappings_hinted(m, reads, mp, use_max_ratio, out, out_node_freq);
             return;
         }
-        if (!use_max_ratio)
-            PHMM_THROW(PHMM_EINVAL, "use_max_ratio = false (fixed top-k frontier) is not built on the GPU path yet; "
-                                    "MultiDbg::generate_mappings always passes true (multi_dbg/posterior.rs:619)");
-        generate_mappings_sparse(m, reads, out, out_node_freq);
+        generate_mappings_sparse(m, reads, out, out_node_freq, use_max_ratio != 0);
     });
 }
 

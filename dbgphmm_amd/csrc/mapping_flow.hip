@@ -263,6 +263,7 @@ struct DenseMapArgs {
     uint32_t *candA_node, *candB_node;  // [lanes][400]
     double *candA_val, *candB_val;
     double ratio_lin;
+    int topk;
     uint32_t *err;
 };
 
@@ -418,9 +419,28 @@ __global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, c
         }
     }
     __syncthreads();
+    if (ma.topk > 0 && n < ma.topk && n < a.N && threadIdx.x == 0) {
+        // to_mapping(k) of a DENSE column always returns k nodes (hint.rs:124-131): fewer than k have a
+        // non-zero probability here, the rest are zero-probability nodes (which ones is unpinned: lowest ids)
+        const int want = ma.topk < a.N ? ma.topk : a.N;
+        const int n0 = n;
+        for (uint32_t k = 0; n < want && k < (uint32_t)a.N; k++) {
+            bool present = false;
+            for (int j = 0; j < n0; j++) present |= ids[j] == k;
+            if (!present) {
+                ids[n] = k;
+                val[n] = 0.0;
+                n++;
+            }
+        }
+        cnt[gi] = -n;  // hand the new length to the other threads
+    }
+    __syncthreads();
+    if (cnt[gi] < 0) n = -cnt[gi];
+    __syncthreads();
     if (threadIdx.x >= 64) return;  // the sort + record write is a single-wave job
     const uint64_t pidx = ma.lane_pos0[gi] + (uint64_t)(mi - 1);
-    if (!emit_mapping<KMAX>(ma.mpool, pidx, ids, val, n, ma.ratio_lin, true, order)) {
+    if (!emit_mapping<KMAX>(ma.mpool, pidx, ids, val, n, ma.ratio_lin, true, order, ma.topk)) {
         if (threadIdx.x == 0) atomicOr(&ma.err[gi], SP_ERR_POOL);
     }
     if (threadIdx.x == 0) cnt[gi] = 0;
@@ -536,6 +556,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             ba.map_pos0 = (const uint64_t *)(cp + o_gp0);
             ba.lanes = (const uint32_t *)(cp + o_lanes);
             ba.ratio_lin = mc.ratio_lin;
+            ba.topk = mc.topk;
             ba.err = (uint32_t *)(cp + o_err);
             ba.stop = (int *)(cp + o_stop);
             ba.hand = (BHandoff *)(cp + o_hand);
@@ -544,7 +565,8 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             std::vector<uint32_t> todo = sparse_lanes;
             std::vector<int> hstop(lanes);
             std::vector<uint32_t> herr2(lanes);
-            const bool lean_ok = m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
+            const bool lean_ok =
+                mc.topk == 0 && m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
             for (int round = 0; round < 64 && !todo.empty(); round++) {
                 const bool small = (round & 1) == 0;
                 HIP_CHECK(hipMemcpyAsync(cp + o_lanes, todo.data(), sizeof(uint32_t) * todo.size(), hipMemcpyHostToDevice, s));
@@ -605,6 +627,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.candB_node = (uint32_t *)(cp + o_bn);
         ma.candB_val = (double *)(cp + o_bv);
         ma.ratio_lin = mc.ratio_lin;
+        ma.topk = mc.topk;
         ma.err = (uint32_t *)(cp + o_err);
         const bool st_on = W == 64;  // statistics of bwd_step<64> only (bench.py's roofline)
         LaunchTimer lt(timing_enabled() && st_on);
@@ -696,13 +719,15 @@ __global__ void __launch_bounds__(BLOCK) map_node_freq(const uint32_t *sorted_no
     freq[v] = s;
 }
 
-static void init_sink(phmm_model *m, const phmm_reads *reads, MappingSink &sink) {
+static void init_sink(phmm_model *m, const phmm_reads *reads, MappingSink &sink, int topk = 0) {
     hipStream_t s = current_stream();
     const uint64_t n_pos = reads->total;
     sink.reads = reads;
     sink.total_pos = n_pos;
     // (+ 2 x 64 KB per read: the frontier kernels claim the pool in 32 KB slabs per wave)
-    sink.cap = std::max<uint64_t>(m->wset().aux[5].bytes, n_pos * 160 + reads->R * 131072 + (1u << 20));
+    // ratio lists hold ~5 entries per position; fixed lists exactly topk
+    const uint64_t per_pos = topk > 0 ? 16 + 12 * (uint64_t)topk : 160;
+    sink.cap = std::max<uint64_t>(m->wset().aux[5].bytes, n_pos * per_pos + reads->R * 131072 + (1u << 20));
     m->wset().aux[5].reserve(sink.cap);
     m->wset().aux[6].reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1));
     HIP_CHECK(hipMemsetAsync(m->wset().aux[6].p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1), s));
@@ -782,14 +807,15 @@ static void finish_mappings(phmm_model *m, const phmm_reads *reads, MappingSink 
 }
 
 // PHMMModel::generate_mappings(reads, None, use_max_ratio = true)
-void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq) {
+void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq,
+                              bool by_ratio) {
     MappingSink sink{};
     std::vector<double> lf(reads->R);
     double tot = 0.0;
     for (int attempt = 0;; attempt++) {
-        init_sink(m, reads, sink);
+        init_sink(m, reads, sink, by_ratio ? 0 : (int)m->params.n_active_nodes);
         try {
-            full_prob_reads_sparse(m, reads, lf.data(), &tot, &sink);
+            full_prob_reads_sparse(m, reads, lf.data(), &tot, &sink, by_ratio);
             break;
         } catch (const SinkOverflow &) {
             if (attempt >= 4) PHMM_THROW(PHMM_ENOMEM, "mapping pool keeps overflowing");

@@ -280,9 +280,11 @@ void upload_mappings(const phmm_mappings *mp);
 void generate_mappings_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp_in, int use_max_ratio,
                               phmm_mappings **out, double *out_node_freq);
 struct MappingSink;
+// by_ratio: use_max_ratio of forward_sparse (forward.rs:93-154); false = fixed warm-up + top n_active_nodes
 void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total,
-                            MappingSink *sink);
-void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq);
+                            MappingSink *sink, bool by_ratio = true);
+void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappings **out, double *out_node_freq,
+                              bool by_ratio = true);
 void ensure_logib(phmm_model *m, size_t len);
 void put_doubles(double *dst, const double *src_host, size_t n);
 void dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i,

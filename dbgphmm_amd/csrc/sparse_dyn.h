@@ -175,6 +175,7 @@ struct MapChunk {
     double *d_logp_sparse;
     uint32_t *cand_node;  // [lanes][400] scratch
     double *cand_tot;
+    int topk;  // > 0: to_mapping(topk) instead of to_mapping_by_score_ratio
     std::mutex *dense_token;  // held while the chunk runs its HBM-bound dense backward (sparse_dyn.hip)
 };
 

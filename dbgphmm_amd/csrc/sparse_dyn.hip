@@ -247,6 +247,7 @@ struct Top400Args {
     double *cand_tot;
     int *cand_n;
     double ratio_lin;
+    int K;  // entries kept: 400 (ArrayVec capacity) or n_active_nodes (top_nodes, table.rs:127-131)
 };
 
 __global__ void __launch_bounds__(BLOCK) select_top400(const Top400Args a) {
@@ -277,7 +278,16 @@ __global__ void __launch_bounds__(BLOCK) select_top400(const Top400Args a) {
     __threadfence_block();
     __syncthreads();
     const int n = a.sc_n[blockIdx.x];
-    const int K = PHMM_MAX_ACTIVE_NODES;
+    const int K = a.K;
+    if (n <= K) {
+        // fewer qualify than are asked for: all of them
+        for (int j = threadIdx.x; j < n; j += BLOCK) {
+            a.cand_node[(size_t)gi * PHMM_MAX_ACTIVE_NODES + j] = sn[j];
+            a.cand_tot[(size_t)gi * PHMM_MAX_ACTIVE_NODES + j] = stt[j];
+        }
+        if (threadIdx.x == 0) a.cand_n[gi] = n;
+        return;
+    }
     // largest T with count(v >= T) >= K   (bit patterns of positive doubles are ordered)
     unsigned long long lo = 0ull, hi = (unsigned long long)__double_as_longlong(tmax);
     while (lo < hi) {
@@ -312,8 +322,8 @@ __global__ void __launch_bounds__(BLOCK) select_top400(const Top400Args a) {
         if (b > T || (b == T && sn[j] <= blo)) {
             const int s = atomicAdd(&cnt, 1);
             if (s < K) {
-                a.cand_node[(size_t)gi * K + s] = sn[j];
-                a.cand_tot[(size_t)gi * K + s] = stt[j];
+                a.cand_node[(size_t)gi * PHMM_MAX_ACTIVE_NODES + s] = sn[j];
+                a.cand_tot[(size_t)gi * PHMM_MAX_ACTIVE_NODES + s] = stt[j];
             }
         }
     }
@@ -343,7 +353,7 @@ void launch_col_count_w(int W, const WarmArgs &wa, int col) {
 
 // PHMMModel::to_full_prob_reads without mappings: forward_sparse_score_only(use_max_ratio = true)
 void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total,
-                            MappingSink *sink) {
+                            MappingSink *sink, bool by_ratio) {
     stats() = CallStats();
     const uint64_t R = reads->R;
     if (m->dev.max_degree > 8)
@@ -525,7 +535,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         wa.undecided = (int *)(wp + o_und);
         wa.n_amb = wa.undecided + 1;
         wa.amb = (int *)(wp + o_amb);
-        a.wf_sw = wa.sw;
+        a.wf_sw = by_ratio ? wa.sw : nullptr;
         a.wf_mode = (const uint8_t *)(wp + o_mode);
         a.wf_sub = (int *)(wp + o_wsub);
         a.wf_cnt = (int *)(wp + o_wcnt);
@@ -549,7 +559,22 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock(dense_token, std::defer_lock);
         if (W >= 32) dense_lock.lock();  // narrow plans (deferred reads) do not load the memory system
-        for (;; pos++) {
+        if (!by_ratio) {
+            // not adaptive (forward.rs:134-137): the first n_warmup tables are dense for every read; launch
+            // min(n_warmup, Lc) completes column n_warmup-1 (its Del values) or ends the short reads
+            const int last = std::min<int>((int)prm.n_warmup, Lc);
+            for (pos = 0; pos <= last; pos++) {
+                lt.begin();
+                launch_fwd_step(W, a, pos);
+                lt.end();
+                if (st_on) st.launches[0]++;
+            }
+            std::vector<int> fsw(lanes);
+            for (int gi = 0; gi < lanes; gi++) fsw[gi] = std::min<int>((int)prm.n_warmup, hl[gi]);
+            HIP_CHECK(hipMemcpyAsync(wa.sw, fsw.data(), sizeof(int) * lanes, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+        for (; by_ratio; pos++) {
             lt.begin();
             launch_fwd_step(W, a, pos);  // column pos (if pos < Lc), d + totals maximum of column pos-1
             lt.end();
@@ -601,15 +626,17 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             if (hl[gi] == 0) continue;
             dense_cells += (uint64_t)std::min(hsw[gi] + 1, hl[gi]) * m->N;
             if (hsw[gi] < hl[gi]) {
-                if (hcn[gi] > PHMM_MAX_ACTIVE_NODES) need400.push_back((uint32_t)gi);
+                // ratio mode: a forced switch with more than 400 nodes inside the ratio; fixed mode: always
+                // (top_nodes(n_active_nodes) of the last dense column)
+                if (!by_ratio || hcn[gi] > PHMM_MAX_ACTIVE_NODES) need400.push_back((uint32_t)gi);
                 sparse_lanes.push_back((uint32_t)gi);
             }
         }
         if (st_on) st.cells[0] += dense_cells;
         DevBuf sel;
-        if (!need400.empty()) {
-            // forced switch at n_warmup with > 400 nodes inside the ratio: keep the 400 best
-            const size_t nn = need400.size();
+        for (size_t nb0 = 0; nb0 < need400.size(); nb0 += 256) {
+            // keep the K best of the switch column (scratch: N candidates per read, 256 reads at a time)
+            const size_t nn = std::min<size_t>(256, need400.size() - nb0);
             size_t sb = 0;
             auto c2 = [&](size_t bytes) {
                 sb = (sb + 255) / 256 * 256;
@@ -621,7 +648,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                          p_node = c2(sizeof(uint32_t) * nn * m->N), p_tot = c2(sizeof(double) * nn * m->N);
             sel.reserve(sb);
             char *sp = (char *)sel.p;
-            HIP_CHECK(hipMemcpyAsync(sp + p_need, need400.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(sp + p_need, need400.data() + nb0, sizeof(uint32_t) * nn, hipMemcpyHostToDevice, s));
             Top400Args ta{};
             ta.d = a;
             ta.W = W;
@@ -633,7 +660,8 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             ta.cand_node = wa.cand_node;
             ta.cand_tot = wa.cand_tot;
             ta.cand_n = wa.cand_n;
-            ta.ratio_lin = wa.ratio_lin;
+            ta.ratio_lin = by_ratio ? wa.ratio_lin : 0.0;
+            ta.K = by_ratio ? PHMM_MAX_ACTIVE_NODES : (int)std::min<int64_t>(prm.n_active_nodes, PHMM_MAX_ACTIVE_NODES);
             hipLaunchKernelGGL(select_top400, dim3((unsigned)nn), dim3(BLOCK), 0, s, ta);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipStreamSynchronize(s));
@@ -660,6 +688,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             fa.bases = (const uint8_t *)(wp + o_bases);
             fa.Lb = Lfull;
             fa.ratio_lin = wa.ratio_lin;
+            fa.topk = by_ratio ? 0 : (int)std::min<int64_t>(prm.n_active_nodes, PHMM_MAX_ACTIVE_NODES);
             fa.out_logp = (double *)(wp + o_out);
             fa.err = (uint32_t *)(wp + o_err);
             // table storage for generate_mappings: one record per sparse position
@@ -688,7 +717,8 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 std::vector<uint32_t> herr(lanes);
                 std::vector<int> hstop(lanes);
                 bool pool_full = false;
-                const bool lean_ok = m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
+                const bool lean_ok =
+                    by_ratio && m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
                 for (int round = 0; round < 64 && !todo.empty() && !pool_full; round++) {
                     // round 0: A <400> from the dense column; then B <64> to the end, and for the reads
                     // it could not hold a short C <400> burst followed by B again
@@ -748,7 +778,8 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 mc.hl = &hl;
                 mc.hsw = &hsw;
                 mc.lane_pos0 = &lane_pos0;
-                mc.ratio_lin = wa.ratio_lin;
+                mc.ratio_lin = by_ratio ? wa.ratio_lin : 0.0;
+                mc.topk = by_ratio ? 0 : (int)std::min<int64_t>(prm.n_active_nodes, PHMM_MAX_ACTIVE_NODES);
                 mc.d_logp_sparse = fa.out_logp;
                 mc.cand_node = wa.cand_node;
                 mc.cand_tot = wa.cand_tot;
@@ -776,7 +807,8 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             mc.hl = &hl;
             mc.hsw = &hsw;
             mc.lane_pos0 = &lane_pos0;
-            mc.ratio_lin = wa.ratio_lin;
+            mc.ratio_lin = by_ratio ? wa.ratio_lin : 0.0;
+                mc.topk = by_ratio ? 0 : (int)std::min<int64_t>(prm.n_active_nodes, PHMM_MAX_ACTIVE_NODES);
             mc.d_logp_sparse = (double *)(wp + o_out);
             mc.cand_node = wa.cand_node;
             mc.cand_tot = wa.cand_tot;
@@ -859,7 +891,9 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     };
 
     {
-        std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan(m, reads, 0), 20, true, {}});
+        // fixed mode: every read keeps all n_warmup dense columns, nothing is deferred
+        std::unique_ptr<PlanCtx> pc(
+            new PlanCtx{make_plan(m, reads, 0), by_ratio ? (int64_t)20 : (int64_t)prm.n_warmup + 2, by_ratio, {}});
         // few groups: one worker (the calling thread, on the caller's stream)
         int min_groups = 8;
         if (const char *e = std::getenv("PHMM_PIPELINE_MIN_GROUPS")) min_groups = std::max(1, std::atoi(e));

@@ -34,6 +34,7 @@ struct SparseFwdArgs {
     const uint64_t *lane_pos0;  // [ng*W] first position index of each lane
     int mode;          // 0: start at the switch column from the dense tables; 1: resume
     int max_steps;     // mode 0: positions to walk at most (0 = to the end of the read)
+    int topk;          // > 0: top_nodes(topk) instead of top_nodes_by_score_ratio (use_max_ratio = false)
     int *stop;         // [ng*W] in (mode 1): first position to compute; out: first position NOT done
 };
 
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(64) sparse_forward_kernel(const SparseFwdArgs 
     for (; pos < end && !err; pos++) {
         FVec<CAP> &prev = cols[(pos + 1) & 1];
         FVec<CAP> &cur = cols[pos & 1];
-        select_top<CAP>(prev, cur, sc, true, a.ratio_lin, 0);
+        select_top<CAP>(prev, cur, sc, a.topk == 0, a.ratio_lin, a.topk);
         PrevRef<CAP> p2{};
         p2.vec = &prev;
         p2.E = prev.E;

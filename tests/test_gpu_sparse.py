@@ -159,10 +159,37 @@ def test_adaptive_sparse_forward_matches_oracle(gpu_lib, oracle, cfg):
     assert abs(lf.sum() - tot) < 1e-4 * len(reads)  # hmmv2/tests/dbg.rs:44-45
 
 
-def test_adaptive_sparse_top_k_mode_is_rejected(gpu_lib, oracle):
-    arrays, sg, reads, om, mp = _setup(oracle, n_reads=2)
-    with pytest.raises(D.PhmmError):
-        D.PHMMModel(arrays).to_full_prob_reads(D.ReadCollection(reads), None, False)
+@pytest.mark.parametrize("cfg", [(600, 12, 0.01, 3, 40), (900, 16, 0.003, 21, 12), (300, 12, 0.001, 9, 5)])
+def test_fixed_top_k_forward_matches_oracle(gpu_lib, oracle, cfg):
+    """to_full_prob_reads(reads, None, false) = forward_sparse_score_only(use_max_ratio = false)
+    (forward.rs:158-206): dense for the first n_warmup positions, then the n_active_nodes best."""
+    gl, k, p, seed, n_active = cfg
+    arrays, sg = small_dbg_model(gl, k, p, seed=seed)
+    arrays.param = arrays.param.with_(n_active_nodes=n_active)
+    reads = D.sample_reads(arrays, 10 ** 9, 150, seed=seed + 1, max_reads=30)
+    reads = [r[: max(3, len(r) - (j * 11) % 145)] for j, r in enumerate(reads)]  # some end inside the warm-up
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    tot, lp = gm.to_full_prob_reads(rc, None, False)
+    olp = om.full_prob_reads(reads, None, False, n_threads=8)
+    assert np.max(np.abs(lp - olp)) < 1e-6, np.abs(lp - olp).max()
+
+
+@pytest.mark.parametrize("cfg", [(600, 12, 0.01, 3, 40), (300, 12, 0.001, 9, 6)])
+def test_fixed_top_k_generate_mappings_matches_oracle(gpu_lib, oracle, cfg):
+    """generate_mappings(reads, None, false) = run_sparse_adaptive(false) + to_mapping(n_active_nodes)
+    (hint.rs:193-220, 124-131)."""
+    gl, k, p, seed, n_active = cfg
+    arrays, sg = small_dbg_model(gl, k, p, seed=seed, min_copy_num=1)
+    arrays.param = arrays.param.with_(n_active_nodes=n_active)
+    reads = D.sample_reads(arrays, 10 ** 9, 120, seed=seed + 1, max_reads=16)
+    reads = [r[: max(1, len(r) - (j * 13) % 115)] for j, r in enumerate(reads)]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    mp, nf = gm.generate_mappings(rc, None, False)
+    omp, onf = om.generate_mappings(reads, None, False, n_threads=8)
+    _compare_mappings(reads, mp.arrays(), omp, top_k=n_active)
+    assert abs(nf.sum() - onf.sum()) < 1e-6 * max(1.0, onf.sum())
 
 
 def _compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6, top_k=0):
