@@ -31,6 +31,10 @@
 
 #include "dense_internal.h"
 
+#ifndef PHMM_BWD_PF
+#define PHMM_BWD_PF 1
+#endif
+
 namespace phmm {
 
 
@@ -38,6 +42,22 @@ __device__ __forceinline__ int xcd_block(int b, int nblk8) {
     // physical block b runs on XCD (b % 8); give each XCD a contiguous node range.
     int per = nblk8 >> 3;
     return (b & 7) * per + (b >> 3);
+}
+
+// Node record through the constant address space: with a wave-uniform index (W = 64) the compiler
+// emits one scalar s_load_dwordx8 instead of per-lane vector loads, which keeps the record out of the
+// vector-memory queue (vmcnt is in order: a record load there would make every use wait for the
+// row prefetches issued after it).
+__device__ __forceinline__ NodeRec load_node(const NodeRec *nodes, int k) {
+    typedef const NodeRec __attribute__((address_space(4))) *KPtr;
+    const KPtr q = (KPtr)(uintptr_t)nodes;
+    NodeRec r;
+    r.init = q[k].init;
+    r.dinit = q[k].dinit;
+    r.tdinit = q[k].tdinit;
+    r.emis = q[k].emis;
+    r.flags = q[k].flags;
+    return r;
 }
 
 // exponent e with v * 2^-e in [0.5, 1) for v > 0 (normal); 0 for v == 0
@@ -157,19 +177,22 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
         const double cb = lp.p_IM * ibs;
         // software pipeline: a ring of PF own-value loads stays in flight -- node k+PF is requested
         // before node k is computed (npt is a multiple of PF; the ring is indexed statically)
+        // The prefetches are UNCONDITIONAL loads of a clamped row (every lane, also past the end of the run):
+        // a load under a branch makes hipcc wait for it on the spot (s_waitcnt vmcnt(0) at the join), which
+        // is what defeated the ring before.  Lanes without work compute on whatever the loads return; every
+        // store and every accumulator below is predicated instead.
         constexpr int PF = 2;
-        const bool ld = have_prev && pos >= 1;
         double rm[PF], ri[PF];
+        const int klast = a.N - 1;
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            int k0 = kbase + u;
+            int k0 = kbase + u < klast ? kbase + u : klast;
             if (W == 64) k0 = __builtin_amdgcn_readfirstlane(k0);
-            rm[u] = ri[u] = 0.0;
-            if (ld && k0 < a.N) {
-                rm[u] = pm[(size_t)k0 * W + r];
-                ri[u] = pi[(size_t)k0 * W + r];
-            }
+            rm[u] = pm[(size_t)k0 * W + r];
+            ri[u] = pi[(size_t)k0 * W + r];
         }
+        NodeRec nr_next = load_node(a.nodes, W == 64 ? __builtin_amdgcn_readfirstlane(kbase < klast ? kbase : klast)
+                                                     : (kbase < klast ? kbase : klast));
         for (int j0 = 0; j0 < a.npt; j0 += PF) {
 #pragma unroll
           for (int u = 0; u < PF; u++) {
@@ -177,13 +200,26 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
             int k = kbase + j;
             if (W == 64) k = __builtin_amdgcn_readfirstlane(k);
             if (k >= a.N) continue;
-            if (!(newcol || have_prev)) continue;
-            const NodeRec nr = a.nodes[k];
+            const NodeRec nr = nr_next;
             const size_t ik = (size_t)k * W + r;
-            const double cur_m = rm[u], cur_i = ri[u];
-            if (ld && j + PF < a.npt && k + PF < a.N) {
-                rm[u] = pm[ik + (size_t)PF * W];
-                ri[u] = pi[ik + (size_t)PF * W];
+            // Take delivery of what was requested earlier -- this node's record (a row ago; scalar loads
+            // return out of order, so a wait placed after the next request would wait for that too) and its
+            // own m, i (PF rows ago) -- BEFORE the next requests go out: the ring slot is then dead when the
+            // new load is issued, the load lands in the same registers, and no copy (= no wait) is needed at
+            // the loop's back edge.
+            const double om = rm[u] * sc, oi = ri[u] * sc;
+            if (W == 64) {
+                asm volatile("" : : "s"(nr.flags), "s"(nr.emis), "v"(om), "v"(oi));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                int kn = k + 1 < klast ? k + 1 : klast;
+                if (W == 64) kn = __builtin_amdgcn_readfirstlane(kn);
+                nr_next = load_node(a.nodes, kn);
+                int kp = k + PF < klast ? k + PF : klast;
+                if (W == 64) kp = __builtin_amdgcn_readfirstlane(kp);
+                rm[u] = pm[(size_t)kp * W + r];
+                ri[u] = pi[(size_t)kp * W + r];
             }
             double mnew, inew = 0.0;
             const double pe = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
@@ -191,7 +227,6 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
                 // f_init: mb = 1, everything else 0 (forward.rs:255-266)
                 mnew = pe * nr.init * lp.p_MM;
             } else {
-                const double om = cur_m * sc, oi = cur_i * sc;
                 double m1, i1, dacc, tacc;
                 if (nr.flags & CHAIN_F) {
                     if (nvalid < H) {
@@ -228,12 +263,12 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
                 }
                 const double dprev = dacc + c * nr.dinit;
                 const double td = tacc + c * nr.tdinit;
-                pd[ik] = dprev * isc;  // stored in column pos-1's own exponent
+                if (have_prev) pd[ik] = dprev * isc;  // stored in column pos-1's own exponent
                 mnew = pe * (lp.p_MM * m1 + lp.p_IM * i1 + lp.p_DM * td + nr.init * cb);
                 inew = lp.p_random * (lp.p_MI * om + lp.p_II * oi + lp.p_DI * dprev);
                 const double tk = om + oi + dprev;
                 if (want_e) esum += tk;
-                tmax = fmax(tmax, tk);
+                if (have_prev) tmax = fmax(tmax, tk);
                 if (tk > thrL) {
                     // (rare) inside the score ratio of the column maximum, as far as this launch can tell
                     nsub += tk > thrU ? 1 : 0;
@@ -431,45 +466,52 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
         const double pdd1 = lp.p_DD, pdd2 = pdd1 * pdd1, pdd3 = pdd2 * pdd1, pdd4 = pdd2 * pdd2;
 #pragma unroll
         for (int h = 0; h < H; h++) wh[h] = wq[h] = 0.0;
-        // software pipeline: own B values and the F column of node v-1 are loaded before node v
-        // is computed
+        // software pipeline: a ring of PFB rows (own B values of column pos+1 and the F column of the
+        // posterior) stays in flight -- row j-PFB is requested before row j is computed
+        constexpr int PFB = PHMM_BWD_PF;
         const bool ldb = live && !first, ldf = live && wgt != 0.0;
-        double nx_m = 0.0, nx_i = 0.0, nx_fm = 0.0, nx_fi = 0.0, nx_fd = 0.0;
-        {
-            int v0 = kbase + a.npt - 1;
-            if (v0 >= a.N) v0 = a.N - 1;
+        double nx_m[PFB], nx_i[PFB], nx_fm[PFB], nx_fi[PFB], nx_fd[PFB];
+        // rows kbase+jtop .. kbase (jtop clamps the last block of the column)
+        const int jtop = a.npt - 1 < a.N - 1 - kbase ? a.npt - 1 : a.N - 1 - kbase;
+#pragma unroll
+        for (int u = 0; u < PFB; u++) {
+            nx_m[u] = nx_i[u] = nx_fm[u] = nx_fi[u] = nx_fd[u] = 0.0;
+            int v0 = kbase + jtop - u;
             if (W == 64) v0 = __builtin_amdgcn_readfirstlane(v0);
-            if (v0 >= kbase) {
+            if (jtop - u >= 0) {
                 const size_t i0 = (size_t)v0 * W + r;
                 if (ldb) {
-                    nx_m = nm[i0];
-                    nx_i = ni[i0];
+                    nx_m[u] = nm[i0];
+                    nx_i[u] = ni[i0];
                 }
                 if (ldf) {
-                    nx_fm = fm[i0];
-                    nx_fi = fi[i0];
-                    nx_fd = fd[i0];
+                    nx_fm[u] = fm[i0];
+                    nx_fi[u] = fi[i0];
+                    nx_fd[u] = fd[i0];
                 }
             }
         }
-        for (int j = a.npt - 1; j >= 0; j--) {
+        for (int j0 = jtop; j0 >= 0; j0 -= PFB) {
+#pragma unroll
+          for (int u = 0; u < PFB; u++) {
+            const int j = j0 - u;
+            if (j < 0) continue;
             int v = kbase + j;
             if (W == 64) v = __builtin_amdgcn_readfirstlane(v);
-            if (v >= a.N) continue;
             double contrib = 0.0;
             if (live) {
                 const NodeRec nr = a.nodes[v];
                 const size_t iv = (size_t)v * W + r;
-                const double cur_m = nx_m, cur_i = nx_i, cur_fm = nx_fm, cur_fi = nx_fi, cur_fd = nx_fd;
-                if (j > 0) {
+                const double cur_m = nx_m[u], cur_i = nx_i[u], cur_fm = nx_fm[u], cur_fi = nx_fi[u], cur_fd = nx_fd[u];
+                if (j - PFB >= 0) {
                     if (ldb) {
-                        nx_m = nm[iv - W];
-                        nx_i = ni[iv - W];
+                        nx_m[u] = nm[iv - (size_t)PFB * W];
+                        nx_i[u] = ni[iv - (size_t)PFB * W];
                     }
                     if (ldf) {
-                        nx_fm = fm[iv - W];
-                        nx_fi = fi[iv - W];
-                        nx_fd = fd[iv - W];
+                        nx_fm[u] = fm[iv - (size_t)PFB * W];
+                        nx_fi[u] = fi[iv - (size_t)PFB * W];
+                        nx_fd[u] = fd[iv - (size_t)PFB * W];
                     }
                 }
                 const double m0 = first ? lp.p_end : cur_m * sc;
@@ -550,6 +592,7 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
                 const double tot = lanes_sum<W>(contrib);
                 if (r == 0) a.accg[(size_t)g * a.N + v] += tot;
             }
+          }
         }
     }
     const double bmx = block_reduce_rows<W>(vmax, OpMax(), lds);
