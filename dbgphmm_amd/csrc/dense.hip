@@ -467,29 +467,34 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
 #pragma unroll
         for (int h = 0; h < H; h++) wh[h] = wq[h] = 0.0;
         // software pipeline: a ring of PFB rows (own B values of column pos+1 and the F column of the
-        // posterior) stays in flight -- row j-PFB is requested before row j is computed
+        // posterior) stays in flight.  As in fwd_step the loads are unconditional (clamped rows, every
+        // lane; pointers that a launch does not use alias a valid plane) and a ring slot is consumed before
+        // it is requested again, so that hipcc neither waits at a join nor copies at the back edge:
+        // B values are consumed at the top of a row and re-requested there, F values at its end.
         constexpr int PFB = PHMM_BWD_PF;
-        const bool ldb = live && !first, ldf = live && wgt != 0.0;
         double nx_m[PFB], nx_i[PFB], nx_fm[PFB], nx_fi[PFB], nx_fd[PFB];
+        const double *lfm = want_post ? fm : nm, *lfi = want_post ? fi : nm, *lfd = want_post ? fd : nm;
         // rows kbase+jtop .. kbase (jtop clamps the last block of the column)
         const int jtop = a.npt - 1 < a.N - 1 - kbase ? a.npt - 1 : a.N - 1 - kbase;
 #pragma unroll
         for (int u = 0; u < PFB; u++) {
-            nx_m[u] = nx_i[u] = nx_fm[u] = nx_fi[u] = nx_fd[u] = 0.0;
-            int v0 = kbase + jtop - u;
+            int v0 = kbase + (jtop - u > 0 ? jtop - u : 0);
             if (W == 64) v0 = __builtin_amdgcn_readfirstlane(v0);
-            if (jtop - u >= 0) {
-                const size_t i0 = (size_t)v0 * W + r;
-                if (ldb) {
-                    nx_m[u] = nm[i0];
-                    nx_i[u] = ni[i0];
-                }
-                if (ldf) {
-                    nx_fm[u] = fm[i0];
-                    nx_fi[u] = fi[i0];
-                    nx_fd[u] = fd[i0];
-                }
+            const size_t i0 = (size_t)v0 * W + r;
+            nx_m[u] = nx_i[u] = nx_fm[u] = nx_fi[u] = nx_fd[u] = 0.0;
+            if (jtop >= 0) {
+                nx_m[u] = nm[i0];
+                nx_i[u] = ni[i0];
+                nx_fm[u] = lfm[i0];
+                nx_fi[u] = lfi[i0];
+                nx_fd[u] = lfd[i0];
             }
+        }
+        NodeRec nr_next{};
+        if (jtop >= 0) {
+            int v0 = kbase + jtop;
+            if (W == 64) v0 = __builtin_amdgcn_readfirstlane(v0);
+            nr_next = load_node(a.nodes, v0);
         }
         for (int j0 = jtop; j0 >= 0; j0 -= PFB) {
 #pragma unroll
@@ -499,23 +504,26 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
             int v = kbase + j;
             if (W == 64) v = __builtin_amdgcn_readfirstlane(v);
             double contrib = 0.0;
-            if (live) {
-                const NodeRec nr = a.nodes[v];
+            {
+                const NodeRec nr = nr_next;
                 const size_t iv = (size_t)v * W + r;
-                const double cur_m = nx_m[u], cur_i = nx_i[u], cur_fm = nx_fm[u], cur_fi = nx_fi[u], cur_fd = nx_fd[u];
-                if (j - PFB >= 0) {
-                    if (ldb) {
-                        nx_m[u] = nm[iv - (size_t)PFB * W];
-                        nx_i[u] = ni[iv - (size_t)PFB * W];
-                    }
-                    if (ldf) {
-                        nx_fm[u] = fm[iv - (size_t)PFB * W];
-                        nx_fi[u] = fi[iv - (size_t)PFB * W];
-                        nx_fd[u] = fd[iv - (size_t)PFB * W];
-                    }
+                const double cur_m = nx_m[u] * sc, cur_i = nx_i[u] * sc;
+                if (W == 64) {
+                    asm volatile("" : : "s"(nr.flags), "s"(nr.emis), "v"(cur_m), "v"(cur_i));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                const double m0 = first ? lp.p_end : cur_m * sc;
-                const double q0 = lp.p_random * (first ? lp.p_end : cur_i * sc);
+                {
+                    int vn = v - 1 > kbase ? v - 1 : kbase;
+                    if (W == 64) vn = __builtin_amdgcn_readfirstlane(vn);
+                    nr_next = load_node(a.nodes, vn);
+                    int vp = v - PFB > kbase ? v - PFB : kbase;
+                    if (W == 64) vp = __builtin_amdgcn_readfirstlane(vp);
+                    nx_m[u] = nm[(size_t)vp * W + r];
+                    nx_i[u] = ni[(size_t)vp * W + r];
+                }
+                const double cur_fm = nx_fm[u], cur_fi = nx_fi[u], cur_fd = nx_fd[u];
+                const double m0 = first ? lp.p_end : cur_m;
+                const double q0 = lp.p_random * (first ? lp.p_end : cur_i);
                 const double ev = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
                 double a1, ad, at, qd, qt;
                 if (nr.flags & CHAIN_B) {
@@ -566,18 +574,28 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
                 const double td = lp.p_DM * at + lp.p_DI * qt;
                 const double m = lp.p_MM * a1 + lp.p_MD * td + lp.p_MI * q0;
                 const double i = lp.p_IM * a1 + lp.p_ID * td + lp.p_II * q0;
-                om[iv] = m;
-                oi[iv] = i;
-                if (od) od[iv] = d;
-                vmax = fmax(vmax, fmax(m, i));
-                const double in = nr.init;
-                s1 += in * (lp.p_MM * ev * m0 + lp.p_MD * d);
-                s2 += in * (lp.p_IM * ev * m0 + lp.p_ID * d);
+                if (live) {
+                    om[iv] = m;
+                    oi[iv] = i;
+                    if (od) od[iv] = d;
+                    vmax = fmax(vmax, fmax(m, i));
+                    const double in = nr.init;
+                    s1 += in * (lp.p_MM * ev * m0 + lp.p_MD * d);
+                    s2 += in * (lp.p_IM * ev * m0 + lp.p_ID * d);
+                }
                 double c1 = 0.0, c2 = 0.0;
                 if (wgt != 0.0) c1 = wgt * (cur_fm * m + cur_fi * i + cur_fd * d);
                 if (wgt2 != 0.0) c2 = wgt2 * (gm[iv] + gi[iv] + gd[iv]);
                 contrib = c1 + c2;
-                if (a.want_map) {
+                {
+                    // this slot's F values are spent: request the row PFB below
+                    int vp = v - PFB > kbase ? v - PFB : kbase;
+                    if (W == 64) vp = __builtin_amdgcn_readfirstlane(vp);
+                    nx_fm[u] = lfm[(size_t)vp * W + r];
+                    nx_fi[u] = lfi[(size_t)vp * W + r];
+                    nx_fd[u] = lfd[(size_t)vp * W + r];
+                }
+                if (a.want_map && live) {
                     // emit probs of merged index pos (and of merged index len when `first`):
                     // kept for post_collect (to_mapping_by_score_ratio, hint.rs:135-142)
                     Pa[iv] = c1;
