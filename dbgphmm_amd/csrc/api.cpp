@@ -65,7 +65,9 @@ uint64_t table_budget(size_t owned) {
     if (g_ws_limit) return g_ws_limit;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)16 << 30;
-    return (uint64_t)(0.8 * (double)(fr + owned));
+    double frac = 0.9;
+    if (const char *e = std::getenv("PHMM_MEM_FRACTION")) frac = std::min(0.95, std::max(0.1, std::atof(e)));
+    return (uint64_t)(frac * (double)(fr + owned));
 }
 
 void copy_out(void *dst, const void *src_dev, size_t bytes) {

@@ -405,6 +405,8 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     // until the frontier kernels are cheaper the pipeline stays opt-in (PHMM_WORKERS=2..4).
     int n_workers = 1;
     if (const char *e = std::getenv("PHMM_WORKERS")) n_workers = std::max(1, std::min(phmm_model::MAX_WORKERS, std::atoi(e)));
+    int64_t warm_cols = 18;  // dense columns kept per read group by the first plan
+    if (const char *e = std::getenv("PHMM_WARM_COLS")) warm_cols = std::max(4, std::atoi(e));
     int chunk_groups = 0;  // 0: automatic
     if (const char *e = std::getenv("PHMM_CHUNK_GROUPS")) chunk_groups = std::max(0, std::atoi(e));
     const uint64_t limit_total = table_budget(m->owned_table_bytes());
@@ -893,7 +895,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     {
         // fixed mode: every read keeps all n_warmup dense columns, nothing is deferred
         std::unique_ptr<PlanCtx> pc(
-            new PlanCtx{make_plan(m, reads, 0), by_ratio ? (int64_t)20 : (int64_t)prm.n_warmup + 2, by_ratio, {}});
+            new PlanCtx{make_plan(m, reads, 0), by_ratio ? warm_cols : (int64_t)prm.n_warmup + 2, by_ratio, {}});
         // few groups: one worker (the calling thread, on the caller's stream)
         int min_groups = 8;
         if (const char *e = std::getenv("PHMM_PIPELINE_MIN_GROUPS")) min_groups = std::max(1, std::atoi(e));
