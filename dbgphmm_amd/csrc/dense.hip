@@ -184,12 +184,14 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
         constexpr int PF = 2;
         double rm[PF], ri[PF];
         const int klast = a.N - 1;
+        const bool lane_on = newcol || have_prev;
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             int k0 = kbase + u < klast ? kbase + u : klast;
             if (W == 64) k0 = __builtin_amdgcn_readfirstlane(k0);
-            rm[u] = pm[(size_t)k0 * W + r];
-            ri[u] = pi[(size_t)k0 * W + r];
+            // (lanes without work read row 0 over and over: a cache hit instead of HBM traffic)
+            rm[u] = pm[(size_t)(lane_on ? k0 : 0) * W + r];
+            ri[u] = pi[(size_t)(lane_on ? k0 : 0) * W + r];
         }
         NodeRec nr_next = load_node(a.nodes, W == 64 ? __builtin_amdgcn_readfirstlane(kbase < klast ? kbase : klast)
                                                      : (kbase < klast ? kbase : klast));
@@ -218,8 +220,8 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
                 nr_next = load_node(a.nodes, kn);
                 int kp = k + PF < klast ? k + PF : klast;
                 if (W == 64) kp = __builtin_amdgcn_readfirstlane(kp);
-                rm[u] = pm[(size_t)kp * W + r];
-                ri[u] = pi[(size_t)kp * W + r];
+                rm[u] = pm[(size_t)(lane_on ? kp : 0) * W + r];
+                ri[u] = pi[(size_t)(lane_on ? kp : 0) * W + r];
             }
             double mnew, inew = 0.0;
             const double pe = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
@@ -480,7 +482,8 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
         for (int u = 0; u < PFB; u++) {
             int v0 = kbase + (jtop - u > 0 ? jtop - u : 0);
             if (W == 64) v0 = __builtin_amdgcn_readfirstlane(v0);
-            const size_t i0 = (size_t)v0 * W + r;
+            // (lanes that are not live read row 0 over and over: a cache hit instead of HBM traffic)
+            const size_t i0 = (size_t)(live ? v0 : 0) * W + r;
             nx_m[u] = nx_i[u] = nx_fm[u] = nx_fi[u] = nx_fd[u] = 0.0;
             if (jtop >= 0) {
                 nx_m[u] = nm[i0];
@@ -518,8 +521,8 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
                     nr_next = load_node(a.nodes, vn);
                     int vp = v - PFB > kbase ? v - PFB : kbase;
                     if (W == 64) vp = __builtin_amdgcn_readfirstlane(vp);
-                    nx_m[u] = nm[(size_t)vp * W + r];
-                    nx_i[u] = ni[(size_t)vp * W + r];
+                    nx_m[u] = nm[(size_t)(live ? vp : 0) * W + r];
+                    nx_i[u] = ni[(size_t)(live ? vp : 0) * W + r];
                 }
                 const double cur_fm = nx_fm[u], cur_fi = nx_fi[u], cur_fd = nx_fd[u];
                 const double m0 = first ? lp.p_end : cur_m;
@@ -591,9 +594,9 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
                     // this slot's F values are spent: request the row PFB below
                     int vp = v - PFB > kbase ? v - PFB : kbase;
                     if (W == 64) vp = __builtin_amdgcn_readfirstlane(vp);
-                    nx_fm[u] = lfm[(size_t)vp * W + r];
-                    nx_fi[u] = lfi[(size_t)vp * W + r];
-                    nx_fd[u] = lfd[(size_t)vp * W + r];
+                    nx_fm[u] = lfm[(size_t)(live ? vp : 0) * W + r];
+                    nx_fi[u] = lfi[(size_t)(live ? vp : 0) * W + r];
+                    nx_fd[u] = lfd[(size_t)(live ? vp : 0) * W + r];
                 }
                 if (a.want_map && live) {
                     // emit probs of merged index pos (and of merged index len when `first`):

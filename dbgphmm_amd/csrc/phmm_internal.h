@@ -197,6 +197,11 @@ struct phmm_reads {
     // lazily uploaded device copies (per device of first use)
     mutable phmm::DevBuf d_bases, d_off;
     mutable bool on_device = false;
+    // dense warm-up columns each read needed in the last adaptive-sparse call on this handle (empty: none
+    // yet).  Only used to GROUP reads with similar warm-up lengths (results do not depend on the grouping):
+    // a read group runs dense columns until its slowest read switches, and rows of 64 reads in which only a
+    // few are still dense cost whole 64-byte sectors per live read.
+    mutable std::vector<uint16_t> warm_hint;
 };
 
 struct phmm_mappings {

@@ -361,6 +361,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     ensure_logib(m, reads->max_len + 1);
     const phmm_params &prm = m->params;
     std::vector<double> lf(R, 0.0);
+    std::vector<uint16_t> new_hint(R, 0);
     upload_reads(reads);
 
     // ---- work items.  A plan is a grouping of reads (W per group, longest first); it is cut into
@@ -378,6 +379,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         int64_t lc_cap;
         bool may_defer;
         DevBuf d_order;
+        uint64_t max_len = 0;
     };
     struct Item {
         PlanCtx *pc;
@@ -414,7 +416,12 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     // cut a plan into items (caller holds `mu` or is the only thread)
     auto enqueue_plan = [&](std::unique_ptr<PlanCtx> pcu, std::deque<Item> &dst) {
         PlanCtx *pc = pcu.get();
-        const Plan &plan = pc->plan;
+        Plan &plan = pc->plan;
+        for (uint32_t rd : plan.order) pc->max_len = std::max<uint64_t>(pc->max_len, reads->off[rd + 1] - reads->off[rd]);
+        if (by_ratio && reads->warm_hint.size() == reads->R)
+            // reads that stayed dense equally long last time share groups (see phmm_reads::warm_hint)
+            std::stable_sort(plan.order.begin(), plan.order.end(),
+                             [&](uint32_t x, uint32_t y) { return reads->warm_hint[x] > reads->warm_hint[y]; });
         const int W = plan.W;
         const size_t NW = (size_t)m->N * W;
         pc->d_order.upload(plan.order.data(), sizeof(uint32_t) * plan.order.size());
@@ -424,15 +431,19 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         const uint64_t limit = limit_total / (uint64_t)n_workers;
         int g0 = 0;
         while (g0 < plan.ng_total) {
-            const uint32_t r0 = plan.order[(size_t)g0 * W];
-            const int Lfull = (int)(reads->off[r0 + 1] - reads->off[r0]);
             // dense columns kept: at most n_warmup (+1 so that the launch that writes d of the last
             // dense column has somewhere to put its speculative next column)
-            const int Lc = (int)std::min<int64_t>(Lfull, std::min<int64_t>(prm.n_warmup + 2, pc->lc_cap));
+            const int Lc = (int)std::min<int64_t>((int64_t)pc->max_len, std::min<int64_t>(prm.n_warmup + 2, pc->lc_cap));
             const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8;
             int ngc = (int)std::min<uint64_t>(plan.ng_total - g0, std::max<uint64_t>(1, limit / std::max<size_t>(per_group, 1)));
             ngc = std::min(ngc, std::max(1, target));
-            dst.push_back(Item{pc, g0, ngc, Lc, Lfull});
+            // longest read of the chunk (the order need not be by length)
+            int Lfull = 1;
+            for (size_t slot = (size_t)g0 * W; slot < std::min<size_t>(plan.order.size(), (size_t)(g0 + ngc) * W); slot++) {
+                const uint32_t rd = plan.order[slot];
+                Lfull = std::max(Lfull, (int)(reads->off[rd + 1] - reads->off[rd]));
+            }
+            dst.push_back(Item{pc, g0, ngc, std::min(Lc, Lfull), Lfull});
             g0 += ngc;
         }
         plans.push_back(std::move(pcu));
@@ -822,6 +833,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             if (slot >= R || hl[gi] == 0) continue;
             const uint32_t rd = plan.order[slot];
             lf[rd] = hsw[gi] < hl[gi] ? slp[gi] : tlf[gi];
+            new_hint[rd] = (uint16_t)std::min(hsw[gi], 65535);
         }
         }
         if (!deferred_ids.empty()) {
@@ -944,6 +956,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         stats() = merged;
     }
     if (first_error) std::rethrow_exception(first_error);
+    if (by_ratio) reads->warm_hint = new_hint;
     double tot = 0.0;
     for (uint64_t r = 0; r < R; r++) tot += lf[r];
     put_doubles(out_logp, lf.data(), R);
