@@ -19,14 +19,23 @@ import os
 from collections import defaultdict
 
 
-def load(d, counter):
+def load(d, counter, last_fraction=1.0):
+    """per kernel: counter values in dispatch order; last_fraction < 1 keeps only the tail (the timed step
+    of a `--warmup 1 --steps 1` run: the first step has no warm-up hints yet and groups the reads differently)"""
     rows = defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] == counter:
-                    rows[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return rows
+                    rows[r["Kernel_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    out = {}
+    for k, v in rows.items():
+        v.sort()
+        vals = [x for _, x in v]
+        if last_fraction < 1.0 and len(vals) >= 2:
+            vals = vals[len(vals) - max(1, int(round(len(vals) * last_fraction))):]
+        out[k] = vals
+    return out
 
 
 def short(name):
@@ -39,6 +48,7 @@ def main():
     for k in ("calib-fetch", "calib-write", "bench-fetch", "bench-write"):
         ap.add_argument("--" + k, required=True)
     ap.add_argument("--calib-bytes", type=float, default=float(2 << 30))
+    ap.add_argument("--last-fraction", type=float, default=1.0)
     ap.add_argument("--out")
     a = ap.parse_args()
     KB = 1024.0
@@ -73,7 +83,7 @@ def main():
     calib["copy3x8_fetch_ratio"] = calib["copy3x8"]["FETCH_SIZE_KB"] * KB * fetch_corr / n3
     calib["copy3x8_write_ratio"] = calib["copy3x8"]["WRITE_SIZE_KB"] * KB * write_corr / n3
 
-    bf, bw = load(a.bench_fetch, "FETCH_SIZE"), load(a.bench_write, "WRITE_SIZE")
+    bf, bw = load(a.bench_fetch, "FETCH_SIZE", a.last_fraction), load(a.bench_write, "WRITE_SIZE", a.last_fraction)
     kernels = {}
     for name in sorted(set(bf) | set(bw)):
         if "phmm::" not in name:
@@ -88,7 +98,7 @@ def main():
             "traffic_bytes_per_launch": fm * KB * fetch_corr + wm * KB * write_corr,
         }
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (kernel-trace only), "
-                     "bench.py --steps 1 --warmup 0 --no-cpu-baseline and tools/pmc_calib",
+                     "bench.py --steps 1 --warmup 1 --no-cpu-baseline (timed step only) and tools/pmc_calib",
            "correction": "bytes = counter[KB] * 1024 * factor; factors from the 8 B/lane streaming kernels of "
                          "tools/pmc_calib.hip (FETCH_SIZE x2, WRITE_SIZE x1 on gfx950)",
            "calibration": calib, "kernels": kernels}
