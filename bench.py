@@ -125,12 +125,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")  # rehearsal only: RCCL refuses two ranks on one device
     dev = torch.device("cuda", local_rank)
 
     import dbgphmm_amd as D
@@ -187,6 +192,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, float(n_bases)], dtype=torch.float64, device=dev)
+    if dist is not None and dist.get_backend() == "gloo":
+        t = t.cpu()
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -44,5 +44,11 @@ def all_reduce_partial(buf, dist=None):
         t = torch.from_numpy(buf)
         dist.all_reduce(t)
         return buf
+    if buf.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device)
+        t = buf.cpu()
+        dist.all_reduce(t)
+        buf.copy_(t)
+        return buf
     dist.all_reduce(buf)
     return buf
