@@ -313,3 +313,43 @@ def test_chunk_pipeline_matches_single_stream(gpu_lib, oracle, monkeypatch):
     assert np.array_equal(mp1.read_logp()[1], mp3.read_logp()[1])
     omp, onf = om.generate_mappings(reads, None, True, n_threads=8)
     _compare_mappings(reads, a3, omp)
+
+
+def test_full_size_properties_cfg3(gpu_lib):
+    """BASELINE.json configs[2] at full size (100 kb diploid, 20x, L = 1000, k = 40: N = 1.3e5, 4e6 bases)
+    through size-independent properties -- the oracle needs minutes for this, the GPU a second."""
+    import bench
+    arrays, reads, w = bench.build_workload("cfg3", 0)
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    n_bases = rc.total_bases()
+    mp, nf = gm.generate_mappings(rc, None, True)
+    po, nd, lp = mp.arrays()
+    cnt = np.diff(po.astype(np.int64))
+    # every position has a non-empty, descending list inside the ratio
+    assert cnt.min() >= 1 and cnt.max() <= 400
+    first = lp[po[:-1].astype(np.int64)]
+    last = lp[po[1:].astype(np.int64) - 1]
+    assert np.all(first - last < 30.0 + 1e-9)
+    seg = np.repeat(np.arange(cnt.shape[0]), cnt)
+    inner = np.ones(lp.shape[0], dtype=bool)
+    inner[po[:-1].astype(np.int64)] = False  # first entry of each list
+    assert np.all(np.diff(lp)[inner[1:]] <= 1e-12)
+    mass = np.bincount(seg, weights=np.exp(lp), minlength=cnt.shape[0])
+    # (Match + Ins emit the base: <= 1; the silent Del states crossed at this index add to it)
+    assert mass.max() < 1.0 + 4.0 and np.median(mass) > 0.99 and mass.min() > 0.0
+    # node usage: about one node per base; equals the sum over the lists
+    assert abs(nf.sum() - n_bases) < 0.01 * n_bases
+    assert abs(nf.sum() - np.exp(lp).sum()) < 1e-6 * n_bases
+    assert np.max(np.abs(mp.to_node_freqs(arrays.n_nodes) - nf)) < 1e-9
+    # the forward score kept with the mappings is the adaptive forward score; the hinted score walks a
+    # subset of its paths (the first positions of a read keep 400 of the ~N nodes inside the ratio): a
+    # little lower, by ~1e-3 per read
+    tot_s, lp_s = gm.to_full_prob_reads(rc, None, True)
+    assert np.array_equal(mp.read_logp()[1], lp_s)
+    tot_h, lp_h = gm.to_full_prob_reads(rc, mp)
+    assert np.all(lp_h <= lp_s + 1e-9) and 0.0 <= tot_s - tot_h < 5e-3 * len(reads)
+    assert np.all(np.isfinite(lp_s)) and lp_s.max() < 0.0
+    # a second call groups the reads differently (warm-up hints) and must return the same bits
+    mp2, nf2 = gm.generate_mappings(rc, None, True)
+    assert all(np.array_equal(x, y) for x, y in zip(mp.arrays(), mp2.arrays())) and np.array_equal(nf, nf2)
