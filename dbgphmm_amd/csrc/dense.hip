@@ -170,7 +170,6 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
         double wg[H];  // g = p_MD m + p_ID i of nodes k-1 .. k-H (prev column, rescaled)
         double wm0 = 0.0, wi0 = 0.0;
         int nvalid = 0;
-        const double pdd1 = lp.p_DD, pdd2 = pdd1 * pdd1, pdd3 = pdd2 * pdd1, pdd4 = pdd2 * pdd2;
 #pragma unroll
         for (int h = 0; h < H; h++) wg[h] = 0.0;
         const double c = lp.p_ID * ibs;  // p_MD*mb + p_ID*ib with mb = 0 (fmb)
@@ -230,25 +229,37 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
                 mnew = pe * nr.init * lp.p_MM;
             } else {
                 double m1, i1, dacc, tacc;
-                if (nr.flags & CHAIN_F) {
-                    if (nvalid < H) {
-                        // run start: fill the window from memory
+                if (a.hop_mode) {
+                    if (!((nr.flags & CHAIN_F) && nvalid)) {
+                        // first node of the run, behind a branch, or a merge: rebuild the per-hop sums
 #pragma unroll
-                        for (int h = 0; h < H; h++) {
-                            const size_t ix = (size_t)(k - 1 - h) * W + r;
+                        for (int h = 0; h < H; h++) wg[h] = 0.0;
+                        wm0 = wi0 = 0.0;
+                        const uint32_t o0 = a.fh_off[k], o1 = a.fh_off[k + 1];
+                        for (uint32_t q = o0; q < o1; q++) {
+                            const HopEntry en = a.fh[q];
+                            const size_t ix = (size_t)en.node * W + r;
                             const double vm = pm[ix] * sc, vi = pi[ix] * sc;
-                            wg[h] = lp.p_MD * vm + lp.p_ID * vi;
-                            if (h == 0) {
-                                wm0 = vm;
-                                wi0 = vi;
+                            const double wgv = en.w * (lp.p_MD * vm + lp.p_ID * vi);
+                            const int hh = (int)(en.hop_emis & 0xff) - 1;
+#pragma unroll
+                            for (int h = 0; h < H; h++)
+                                if (hh == h) wg[h] += wgv;
+                            if (hh == 0) {
+                                wm0 += en.w * vm;
+                                wi0 += en.w * vi;
                             }
                         }
-                        nvalid = H;
+                        nvalid = 1;
                     }
                     m1 = wm0;
                     i1 = wi0;
-                    dacc = wg[0] + pdd1 * wg[1] + pdd2 * wg[2] + pdd3 * wg[3] + pdd4 * wg[4];
-                    tacc = wg[1] + pdd1 * wg[2] + pdd2 * wg[3] + pdd3 * wg[4] + pdd4 * wg[5];
+                    dacc = tacc = 0.0;
+#pragma unroll
+                    for (int h = 0; h < H; h++) {
+                        dacc += a.cD[h] * wg[h];
+                        tacc += a.cT[h] * wg[h];
+                    }
                 } else {
                     m1 = i1 = dacc = tacc = 0.0;
                     const uint32_t o0 = a.fc_off[k], o1 = a.fc_off[k + 1];
@@ -289,7 +300,6 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
                 wg[0] = lp.p_MD * om + lp.p_ID * oi;
                 wm0 = om;
                 wi0 = oi;
-                nvalid = nvalid < H ? nvalid + 1 : H;
             }
             if (newcol) {
                 cm_[ik] = mnew;
@@ -465,7 +475,6 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
         const int kbase = lb * (a.npt * ROWS) + row * a.npt;
         double wh[H], wq[H];  // h, q of nodes v+1 .. v+H (column pos+1, rescaled)
         int nvalid = 0;
-        const double pdd1 = lp.p_DD, pdd2 = pdd1 * pdd1, pdd3 = pdd2 * pdd1, pdd4 = pdd2 * pdd2;
 #pragma unroll
         for (int h = 0; h < H; h++) wh[h] = wq[h] = 0.0;
         // software pipeline: a ring of PFB rows (own B values of column pos+1 and the F column of the
@@ -529,24 +538,38 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
                 const double q0 = lp.p_random * (first ? lp.p_end : cur_i);
                 const double ev = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
                 double a1, ad, at, qd, qt;
-                if (nr.flags & CHAIN_B) {
-                    if (nvalid < H) {
+                if (a.hop_mode) {
+                    if (!((nr.flags & CHAIN_B) && nvalid)) {
+                        // first node of the run, in front of a merge, or a branch node: rebuild the per-hop sums
 #pragma unroll
-                        for (int h = 0; h < H; h++) {
-                            const int u = v + 1 + h;
-                            const size_t ix = (size_t)u * W + r;
+                        for (int h = 0; h < H; h++) wh[h] = wq[h] = 0.0;
+                        const uint32_t o0 = a.bh_off[v], o1 = a.bh_off[v + 1];
+                        for (uint32_t q = o0; q < o1; q++) {
+                            const HopEntry en = a.bh[q];
+                            const size_t ix = (size_t)en.node * W + r;
                             const double mu = first ? lp.p_end : nm[ix] * sc;
                             const double iu = first ? lp.p_end : ni[ix] * sc;
-                            wh[h] = ((uint8_t)a.nodes[u].emis == x ? lp.p_match : lp.p_mismatch) * mu;
-                            wq[h] = lp.p_random * iu;
+                            const double hv = en.w * ((uint8_t)(en.hop_emis >> 8) == x ? lp.p_match : lp.p_mismatch) * mu;
+                            const double qv = en.w * lp.p_random * iu;
+                            const int hh = (int)(en.hop_emis & 0xff) - 1;
+#pragma unroll
+                            for (int h = 0; h < H; h++)
+                                if (hh == h) {
+                                    wh[h] += hv;
+                                    wq[h] += qv;
+                                }
                         }
-                        nvalid = H;
+                        nvalid = 1;
                     }
                     a1 = wh[0];
-                    ad = wh[0] + pdd1 * wh[1] + pdd2 * wh[2] + pdd3 * wh[3] + pdd4 * wh[4];
-                    at = wh[1] + pdd1 * wh[2] + pdd2 * wh[3] + pdd3 * wh[4] + pdd4 * wh[5];
-                    qd = pdd1 * wq[0] + pdd2 * wq[1] + pdd3 * wq[2] + pdd4 * wq[3];
-                    qt = wq[0] + pdd1 * wq[1] + pdd2 * wq[2] + pdd3 * wq[3] + pdd4 * wq[4];
+                    ad = at = qd = qt = 0.0;
+#pragma unroll
+                    for (int h = 0; h < H; h++) {
+                        ad += a.cD[h] * wh[h];
+                        at += a.cT[h] * wh[h];
+                        qd += a.cQ[h] * wq[h];
+                        qt += a.cD[h] * wq[h];
+                    }
                 } else {
                     a1 = ad = at = qd = qt = 0.0;
                     const uint32_t o0 = a.bc_off[v], o1 = a.bc_off[v + 1];
@@ -572,7 +595,6 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
                 }
                 wh[0] = ev * m0;
                 wq[0] = q0;
-                nvalid = nvalid < H ? nvalid + 1 : H;
                 const double d = lp.p_DM * ad + lp.p_DI * (q0 + qd);
                 const double td = lp.p_DM * at + lp.p_DI * qt;
                 const double m = lp.p_MM * a1 + lp.p_MD * td + lp.p_MI * q0;
@@ -946,6 +968,22 @@ void fill_model_args(DenseArgs &a, const phmm_model *m) {
     a.bc_off = d.bc_off.as<uint32_t>();
     a.bc = d.bc_ent.as<BwdEntry>();
     a.lp = m->lin;
+    a.fh_off = d.fh_off.as<uint32_t>();
+    a.fh = d.fh_ent.as<HopEntry>();
+    a.bh_off = d.bh_off.as<uint32_t>();
+    a.bh = d.bh_ent.as<HopEntry>();
+    {
+        const int G = m->lin.n_max_gaps;
+        a.hop_mode = G + 2 <= CHAIN_HOPS ? 1 : 0;
+        double pw[CHAIN_HOPS + 1];
+        pw[0] = 1.0;
+        for (int h = 1; h <= CHAIN_HOPS; h++) pw[h] = pw[h - 1] * m->lin.p_DD;
+        for (int h = 0; h < CHAIN_HOPS; h++) {
+            a.cD[h] = h <= G ? pw[h] : 0.0;                      // hop h+1 <= G+1: p_DD^(hop-1)
+            a.cT[h] = (h >= 1 && h <= G + 1) ? pw[h - 1] : 0.0;  // 2 <= hop <= G+2: p_DD^(hop-2)
+            a.cQ[h] = h + 1 <= G ? pw[h + 1] : 0.0;              // hop <= G: p_DD^hop
+        }
+    }
 }
 
 // forward InsBegin chain in the log domain: ib_0 = p_r*(p_MI*1 + p_II*0); ib_i = p_r*p_II*ib_{i-1}

@@ -21,6 +21,13 @@ struct DenseArgs {
     const FwdEntry *fc;
     const uint32_t *bc_off;
     const BwdEntry *bc;
+    // n_max_gaps <= 4: closure entries by hop + per-thread windows (hop_mode = 1); coefficients of the
+    // per-hop sums A[h] (h = hop-1):  d-closure sum cD[h] A[h], its one-hop-shifted twin sum cT[h] A[h],
+    // and for the backward Ins terms sum cQ[h] Q[h]
+    const uint32_t *fh_off, *bh_off;
+    const HopEntry *fh, *bh;
+    int hop_mode;
+    double cD[CHAIN_HOPS], cT[CHAIN_HOPS], cQ[CHAIN_HOPS];
     LinParams lp;
     const double *logib;  // [Lc] forward InsBegin chain (log)
     // read batch

@@ -122,13 +122,27 @@ void model_upload(phmm_model *m) {
     bc.reserve((size_t)N * 7);
     std::vector<FwdEntry> tmpf;
     std::vector<BwdEntry> tmpb;
+    std::vector<uint32_t> fh_off(N + 1, 0), bh_off(N + 1, 0);
+    std::vector<HopEntry> fh, bh, tmph;
+    fh.reserve((size_t)N * 7);
+    bh.reserve((size_t)N * 7);
+    auto add_hop = [&](uint32_t a, int hop, double w) {
+        for (auto &e : tmph)
+            if (e.node == a && (int)(e.hop_emis & 0xff) == hop) {
+                e.w += w;
+                return;
+            }
+        tmph.push_back(HopEntry{a, (uint32_t)hop | ((uint32_t)m->emission[a] << 8), w});
+    };
     std::vector<NodeRec> nodes(N);
-    const bool chain_ok = G == 4 && H == CHAIN_HOPS;
+    const bool chain_ok = H <= CHAIN_HOPS;  // n_max_gaps <= 4: hop entries + window (dense.hip)
     for (uint32_t k = 0; k < N; k++) {
         tmpf.clear();
+        tmph.clear();
         double di = ilin[k], tdi = 0.0;
         walk_closure(m->par_off, m->par_node, m->par_edge, tlin, k, H,
                      [&](uint32_t a, int hop, double w) {
+                         add_hop(a, hop, w);
                          double w1 = hop == 1 ? w : 0.0;
                          double wD = hop <= G + 1 ? pdd[hop - 1] * w : 0.0;
                          double wT = hop >= 2 ? pdd[hop - 2] * w : 0.0;
@@ -153,27 +167,20 @@ void model_upload(phmm_model *m) {
             max_dinit = std::max(max_dinit, di);
         }
         uint32_t flags = 0;
-        // unitig run: ancestors are exactly k-1 .. k-H, every path weight 1
-        if (chain_ok && k >= (uint32_t)H && tmpf.size() == (size_t)H) {
-            bool ok = true;
-            for (int h = 1; h <= H && ok; h++) {
-                bool found = false;
-                for (const auto &e : tmpf)
-                    if (e.node == k - (uint32_t)h) {
-                        found = e.w1 == (h == 1 ? 1.0 : 0.0) && e.wD == (h <= G + 1 ? pdd[h - 1] : 0.0) &&
-                                e.wT == (h >= 2 ? pdd[h - 2] : 0.0);
-                        break;
-                    }
-                ok = found;
-            }
-            if (ok) flags |= CHAIN_F;
-        }
+        fh.insert(fh.end(), tmph.begin(), tmph.end());
+        fh_off[k + 1] = (uint32_t)fh.size();
+        // the only parent is k-1 over an edge of weight 1: the ancestor window just slides
+        if (chain_ok && k >= 1 && m->par_off[k + 1] - m->par_off[k] == 1 && m->par_node[m->par_off[k]] == k - 1 &&
+            tlin[m->par_edge[m->par_off[k]]] == 1.0)
+            flags |= CHAIN_F;
         fc.insert(fc.end(), tmpf.begin(), tmpf.end());
         fc_off[k + 1] = (uint32_t)fc.size();
 
         tmpb.clear();
+        tmph.clear();
         walk_closure(m->chi_off, m->chi_node, m->chi_edge, tlin, k, H,
                      [&](uint32_t u, int hop, double w) {
+                         add_hop(u, hop, w);
                          double c1 = hop == 1 ? w : 0.0;
                          double cAd = hop <= G + 1 ? pdd[hop - 1] * w : 0.0;
                          double cAt = hop >= 2 ? pdd[hop - 2] * w : 0.0;
@@ -189,20 +196,11 @@ void model_upload(phmm_model *m) {
                              }
                          tmpb.push_back(BwdEntry{u, m->emission[u], c1, cAd, cAt, cQd});
                      });
-        if (chain_ok && (uint64_t)k + H < N && tmpb.size() == (size_t)H) {
-            bool ok = true;
-            for (int h = 1; h <= H && ok; h++) {
-                bool found = false;
-                for (const auto &e : tmpb)
-                    if (e.node == k + (uint32_t)h) {
-                        found = e.c1 == (h == 1 ? 1.0 : 0.0) && e.cAd == (h <= G + 1 ? pdd[h - 1] : 0.0) &&
-                                e.cAt == (h >= 2 ? pdd[h - 2] : 0.0) && e.cQd == (h <= G ? pdd[h] : 0.0);
-                        break;
-                    }
-                ok = found;
-            }
-            if (ok) flags |= CHAIN_B;
-        }
+        bh.insert(bh.end(), tmph.begin(), tmph.end());
+        bh_off[k + 1] = (uint32_t)bh.size();
+        if (chain_ok && (uint64_t)k + 1 < N && m->chi_off[k + 1] - m->chi_off[k] == 1 &&
+            m->chi_node[m->chi_off[k]] == k + 1 && tlin[m->chi_edge[m->chi_off[k]]] == 1.0)
+            flags |= CHAIN_B;
         nodes[k] = NodeRec{ilin[k], dinit[k], tdinit[k], m->emission[k], flags};
         bc.insert(bc.end(), tmpb.begin(), tmpb.end());
         bc_off[k + 1] = (uint32_t)bc.size();
@@ -222,6 +220,10 @@ void model_upload(phmm_model *m) {
     d.fc_ent.upload(fc.data(), sizeof(FwdEntry) * fc.size());
     d.bc_off.upload(bc_off.data(), sizeof(uint32_t) * (N + 1));
     d.bc_ent.upload(bc.data(), sizeof(BwdEntry) * bc.size());
+    d.fh_off.upload(fh_off.data(), sizeof(uint32_t) * (N + 1));
+    d.fh_ent.upload(fh.data(), sizeof(HopEntry) * std::max<size_t>(fh.size(), 1));
+    d.bh_off.upload(bh_off.data(), sizeof(uint32_t) * (N + 1));
+    d.bh_ent.upload(bh.data(), sizeof(HopEntry) * std::max<size_t>(bh.size(), 1));
     // linear-domain CSR for the sparse kernels
     std::vector<double> pw(E), cw(E);
     for (uint32_t a = 0; a < E; a++) {

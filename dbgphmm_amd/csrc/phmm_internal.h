@@ -102,10 +102,23 @@ struct BwdEntry {
     double c1, cAd, cAt, cQd;
 };
 
+// Closure entry by hop (n_max_gaps <= 4): node `node` reaches (is reached from) k in exactly `hop`
+// edges with total path weight w.  The kernels keep, per thread, the per-hop sums
+//   A[h] = sum over entries with hop h+1 of w * value(node)        h = 0 .. CHAIN_HOPS-1
+// ("window") from which every Del-closure term follows with fixed coefficients (DenseArgs::cD ..).
+struct HopEntry {
+    uint32_t node;
+    uint32_t hop_emis;  // hop | emission(node) << 8
+    double w;
+};
+
 // Per-node record of the dense kernels (one 32-byte scalar load per node).
-//   CHAIN_F: the ancestor closure of k is exactly k-1 .. k-CHAIN_HOPS with unit weights
-//   CHAIN_B: the descendant closure of k is exactly k+1 .. k+CHAIN_HOPS with unit weights
-// (k sits on a unitig run whose node ids are consecutive; set only when n_max_gaps == 4)
+//   CHAIN_F: k's only parent is k-1 and that edge has weight 1 -> the window of k is the window of k-1
+//            shifted by one hop with k-1's own values in front (no gather at all)
+//   CHAIN_B: k's only child is k+1, weight 1 (the same for the descendant window)
+// Node ids follow the k-mer order of the haplotypes, so this holds along unitigs AND behind a merge;
+// the window is rebuilt from the hop entries at the first node of a thread's run, behind a branch and
+// at a merge node only.  (n_max_gaps > 4: no flags, merged closure entries, no window.)
 struct NodeRec {
     double init, dinit, tdinit;
     uint32_t emis;
@@ -145,6 +158,8 @@ struct ModelDev {
     DevBuf dinit, tdinit;    // f64[N]
     DevBuf fc_off, fc_ent;   // u32[N+1], FwdEntry[]
     DevBuf bc_off, bc_ent;   // u32[N+1], BwdEntry[]
+    DevBuf fh_off, fh_ent;   // u32[N+1], HopEntry[]  (ancestors by hop)
+    DevBuf bh_off, bh_ent;   // u32[N+1], HopEntry[]  (descendants by hop)
     // parent / child CSR in linear domain for the sparse kernels
     DevBuf par_off, par_node, par_w;  // u32[N+1], u32[E], f64[E]
     DevBuf chi_off, chi_node, chi_w;
