@@ -461,6 +461,21 @@ int phmm_full_prob_reads_copy_nums(phmm_model *m, const phmm_reads *reads, const
     });
 }
 
+int phmm_mappings_map_nodes(phmm_model *model_after, const phmm_reads *reads, const phmm_mappings *mp,
+                            const uint32_t *map_off, const uint32_t *map_nodes, uint32_t n_nodes_before,
+                            phmm_mappings **out) {
+    return guarded([&] {
+        if (!model_after || !reads || !mp || !map_off || !out) PHMM_THROW(PHMM_EINVAL, "NULL argument");
+        *out = nullptr;
+        if (mp->R != reads->R || mp->total_pos != reads->total) PHMM_THROW(PHMM_EINVAL, "mappings do not belong to these reads");
+        if (map_off[0] != 0) PHMM_THROW(PHMM_EINVAL, "map_off[0] must be 0");
+        for (uint32_t v = 0; v < n_nodes_before; v++)
+            if (map_off[v + 1] < map_off[v]) PHMM_THROW(PHMM_EINVAL, "map_off not monotone");
+        if (map_off[n_nodes_before] && !map_nodes) PHMM_THROW(PHMM_EINVAL, "NULL map_nodes");
+        mappings_map_nodes(model_after, reads, mp, map_off, map_nodes, n_nodes_before, out);
+    });
+}
+
 int phmm_generate_mappings(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, int use_max_ratio,
                            phmm_mappings **out, double *out_node_freq) {
     return guarded([&] {

@@ -827,6 +827,168 @@ void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappi
     finish_mappings(m, reads, sink, lf, out, out_node_freq);
 }
 
+// ---------------------------------------------------------------- Mapping::map_nodes
+// Mapping::map_nodes (hint.rs:60-88), the carrier of MultiDbg::hint_kp1_from_hint_k (multi_dbg.rs:1325-1335)
+// and PurgeEdgeMap::update_mapping (multi_dbg.rs:1783-1793): for every read position
+//   m[node_after] += prob / |node_map(node)|  over the position's (node, prob) and node_after in node_map(node),
+// then the MAX_ACTIVE_NODES most probable in descending order.  node_map arrives as a CSR over the OLD nodes.
+// One wave per position; the entries are taken in list order (lanes = the images of one node), so every sum
+// has a fixed order.
+static constexpr int MN_HASH = 4096;  // >= 2 x (400 entries x 5 images)
+struct MapNodesArgs {
+    const uint64_t *pos_off;
+    const uint32_t *nodes;
+    const double *logp;
+    uint64_t n_pos;
+    const uint32_t *map_off, *map_nodes;
+    uint32_t n_old, n_new;
+    RecPool out;
+    uint32_t *err;  // [1]
+};
+__global__ void __launch_bounds__(64) map_nodes_kernel(const MapNodesArgs a) {
+    __shared__ uint32_t keys[MN_HASH];
+    __shared__ double acc[MN_HASH];
+    __shared__ uint16_t cells[MN_HASH / 2];  // claimed cells in insertion order
+    __shared__ int ncell;
+    const uint64_t p = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int h = lane; h < MN_HASH; h += 64) keys[h] = H_EMPTY;
+    if (lane == 0) ncell = 0;
+    __syncthreads();
+    const uint64_t o0 = a.pos_off[p], o1 = a.pos_off[p + 1];
+    uint32_t bad = 0;
+    for (uint64_t j = o0; j < o1; j++) {
+        const uint32_t node = a.nodes[j];
+        if (node >= a.n_old) {
+            bad = 1;
+            continue;
+        }
+        const uint32_t m0 = a.map_off[node], m1 = a.map_off[node + 1];
+        const uint32_t len = m1 - m0;
+        const double v = exp(a.logp[j]) / (double)(len ? len : 1);
+        for (uint32_t q0 = 0; q0 < len; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            int cell = -1;
+            bool fresh = false;
+            if (q < len) {
+                const uint32_t key = a.map_nodes[m0 + q];
+                if (key >= a.n_new) bad = 1;
+                else {
+                    uint32_t h = (key * 2654435761u) >> 20;
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&keys[h], H_EMPTY, key);
+                        if (old == H_EMPTY) {
+                            fresh = true;
+                            acc[h] = 0.0;
+                            break;
+                        }
+                        if (old == key) break;
+                        h = (h + 1) & (MN_HASH - 1);
+                    }
+                    cell = (int)h;
+                }
+            }
+            const unsigned long long fm = __ballot(fresh);
+            const int base = ncell;
+            if (fresh) {
+                const int s = base + __popcll(fm & ((1ull << lane) - 1ull));
+                if (s < MN_HASH / 2) cells[s] = (uint16_t)cell;
+                else bad = 2;
+            }
+            __syncthreads();
+            if (lane == 0) ncell = base + __popcll(fm);
+            // (images of one node are distinct in a well-formed map; a repeated image still adds up, just
+            // through an atomic)
+            if (cell >= 0) atomicAdd(&acc[cell], v);
+            __syncthreads();
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) bad |= (uint32_t)__shfl_xor((int)bad, off);
+    const int n = ncell < MN_HASH / 2 ? ncell : MN_HASH / 2;
+    const int keep = n < PHMM_MAX_ACTIVE_NODES ? n : PHMM_MAX_ACTIVE_NODES;
+    const uint64_t idb = (uint64_t)((keep + 1) & ~1) * 4;
+    const uint64_t bytes = 8 + idb + (uint64_t)keep * 8;
+    const uint64_t o = pool_alloc(a.out, bytes);
+    if (o + bytes > a.out.cap) bad |= 4;
+    if (bad) {
+        if (lane == 0) atomicOr(a.err, bad);
+        return;
+    }
+    uint8_t *rec = a.out.base + o;
+    if (lane == 0) {
+        ((uint32_t *)rec)[0] = (uint32_t)keep;
+        ((uint32_t *)rec)[1] = 0;
+        a.out.off[p] = o + 8;
+    }
+    uint32_t *oid = (uint32_t *)(rec + 8);
+    double *olp = (double *)(rec + 8 + idb);
+    for (int j = lane; j < n; j += 64) {
+        const double v = acc[cells[j]];
+        const uint32_t id = keys[cells[j]];
+        int rank = 0;
+        for (int q = 0; q < n; q++) {
+            const double u = acc[cells[q]];
+            rank += (u > v) || (u == v && keys[cells[q]] < id);
+        }
+        if (rank < keep) {
+            oid[rank] = id;
+            olp[rank] = v > 0.0 ? log(v) : -INFINITY;
+        }
+    }
+}
+
+void mappings_map_nodes(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp_in, const uint32_t *map_off,
+                        const uint32_t *map_nodes, uint32_t n_old, phmm_mappings **out) {
+    hipStream_t s = current_stream();
+    const uint64_t n_pos = reads->total;
+    upload_mappings(mp_in);
+    if (mp_in->d_logp.p == nullptr && mp_in->host_valid)  // host-made mappings upload their probabilities on demand
+        mp_in->d_logp.upload(mp_in->logp.data(), std::max<size_t>(mp_in->logp.size(), 1) * sizeof(double));
+    const uint64_t n_img = map_off[n_old];
+    DevBuf d_off, d_img, d_err;
+    d_off.upload(map_off, sizeof(uint32_t) * ((size_t)n_old + 1));
+    d_img.upload(map_nodes, sizeof(uint32_t) * std::max<uint64_t>(n_img, 1));
+    d_err.reserve(sizeof(uint32_t));
+    HIP_CHECK(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), s));
+    uint32_t max_fan = 1;
+    for (uint32_t v = 0; v < n_old; v++) max_fan = std::max(max_fan, map_off[v + 1] - map_off[v]);
+    MappingSink sink{};
+    init_sink(m, reads, sink);
+    {
+        const uint64_t need = n_pos * 16 + std::min<uint64_t>(mp_in->total_entries * max_fan, n_pos * PHMM_MAX_ACTIVE_NODES) * 12 +
+                              (1u << 20);
+        if (need > sink.cap) {
+            sink.cap = need;
+            m->wset().aux[5].reserve(sink.cap);
+            sink.mp.base = m->wset().aux[5].as<uint8_t>();
+            sink.mp.cap = sink.cap;
+        }
+    }
+    MapNodesArgs a{};
+    a.pos_off = mp_in->d_pos_off.as<uint64_t>();
+    a.nodes = mp_in->d_nodes.as<uint32_t>();
+    a.logp = mp_in->d_logp.as<double>();
+    a.n_pos = n_pos;
+    a.map_off = d_off.as<uint32_t>();
+    a.map_nodes = d_img.as<uint32_t>();
+    a.n_old = n_old;
+    a.n_new = m->N;
+    a.out = sink.mp;
+    a.err = d_err.as<uint32_t>();
+    if (n_pos) hipLaunchKernelGGL(map_nodes_kernel, dim3((unsigned)n_pos), dim3(64), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+    uint32_t herr = 0;
+    HIP_CHECK(hipMemcpyAsync(&herr, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (herr & 1) PHMM_THROW(PHMM_EINVAL, "map_nodes: a node id is out of range");
+    if (herr & 2) PHMM_THROW(PHMM_ECAPACITY, "map_nodes: more than 2048 image nodes at one read position");
+    if (herr & 4) PHMM_THROW(PHMM_EINTERNAL, "map_nodes: output pool exhausted");
+    std::vector<double> lf = mp_in->read_logp;
+    if (lf.size() != reads->R) lf.assign(reads->R, 0.0);
+    finish_mappings(m, reads, sink, lf, out, nullptr);
+    if (mp_in->read_logp.size() != reads->R) (*out)->read_logp.clear();
+}
+
 // PHMMModel::generate_mappings(reads, Some(mappings), use_max_ratio): run_with_mapping
 // (freq.rs:72-76) = forward_with_mapping (forward.rs:51-75) + backward_with_mapping
 // (backward.rs:59-93), then to_mapping_by_score_ratio / to_mapping(n_active) (hint.rs:124-142).

@@ -297,6 +297,8 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
                             uint32_t min_copy_num = 0);
 void upload_reads(const phmm_reads *r);
 void upload_mappings(const phmm_mappings *mp);
+void mappings_map_nodes(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp_in, const uint32_t *map_off,
+                        const uint32_t *map_nodes, uint32_t n_old, phmm_mappings **out);
 void generate_mappings_hinted(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp_in, int use_max_ratio,
                               phmm_mappings **out, double *out_node_freq);
 struct MappingSink;

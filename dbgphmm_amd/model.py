@@ -103,6 +103,17 @@ class Mappings:
         _ffi.check(_ffi.lib().phmm_mappings_read_logp(self._h, _ptr(lp), _ptr(tot)))
         return float(tot[0]), lp
 
+    def map_nodes(self, model_after: "PHMMModel", map_off: np.ndarray, map_nodes: np.ndarray) -> "Mappings":
+        """Mapping::map_nodes (hint.rs:60-88) for every read: carry the lists over to another graph through a
+        node map given as CSR over this mapping's graph (MultiDbg::hint_kp1_from_hint_k,
+        PurgeEdgeMap::update_mapping)."""
+        mo = np.ascontiguousarray(map_off, dtype=np.uint32)
+        mn = np.ascontiguousarray(map_nodes, dtype=np.uint32)
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().phmm_mappings_map_nodes(model_after._h, self.reads._h, self._h, _ptr(mo), _ptr(mn),
+                                                      mo.shape[0] - 1, C.byref(h)))
+        return Mappings(h, self.reads)
+
     def to_node_freqs(self, n_nodes: int) -> np.ndarray:
         """Mappings::to_node_freqs (hint.rs:161-171)"""
         out = np.empty(n_nodes)

@@ -177,6 +177,18 @@ int phmm_full_prob_reads_copy_nums(phmm_model *m, const phmm_reads *reads,
                                    const uint32_t *copy_nums, uint32_t min_copy_num,
                                    double *out_logp, double *out_total);
 
+/* Mapping carry-over between graphs: Mapping::map_nodes (hint.rs:60-88) for every read, the carrier of
+ * MultiDbg::hint_kp1_from_hint_k (multi_dbg.rs:1325-1335: node of the k-HMM -> the k+1-HMM nodes of its
+ * parent edges) and PurgeEdgeMap::update_mapping (multi_dbg.rs:1783-1793: node -> its id after purging, or
+ * nothing).  The node map is a CSR over the nodes of the graph the mappings were made on:
+ * images of node v = map_nodes[map_off[v] .. map_off[v+1]) (ids of `model_after`'s nodes; may be empty).
+ * Per position: prob(image) += prob(node) / |images(node)|, then the 400 most probable, descending.
+ * read_logp of the result is copied from `mappings`. */
+int phmm_mappings_map_nodes(phmm_model *model_after, const phmm_reads *reads,
+                            const phmm_mappings *mappings, const uint32_t *map_off,
+                            const uint32_t *map_nodes, uint32_t n_nodes_before,
+                            phmm_mappings **out);
+
 /* PHMMModel::generate_mappings (hint.rs:193-220): run_with_mapping when `mappings`
  * is given else run_sparse_adaptive(use_max_ratio); then to_mapping_by_score_ratio /
  * to_mapping.  out_node_freq[N] (may be NULL) = Mappings::to_node_freqs. */

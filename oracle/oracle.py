@@ -7,6 +7,7 @@ See oracle/phmm_oracle.h for the citations and the parity-pin statement.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import subprocess
 from typing import List, Optional, Sequence, Tuple
@@ -351,3 +352,24 @@ class Output:
                                          _ptr(r), r.shape[0], _ptr(ef), _ptr(nf)):
             raise RuntimeError(_err())
         return ef[:self.model.n_edges], nf
+
+
+def map_nodes(mapping_arrays, map_off, map_nodes, max_active_nodes: int = 400):
+    """Mapping::map_nodes (src/hmmv2/hint.rs:60-88) on flat CSR mappings (pure Python: small cases only).
+    Per position: m[node_after] += prob / |node_map(node)| (Prob `+=` = log-add, prob.rs:181-197), then the
+    `max_active_nodes` most probable in descending order (ties: by node id here; a HashMap's order there)."""
+    po, nd, lp = mapping_arrays
+    out_off, out_nodes, out_lp = [0], [], []
+    for p in range(len(po) - 1):
+        acc = {}
+        for j in range(int(po[p]), int(po[p + 1])):
+            a0, a1 = int(map_off[nd[j]]), int(map_off[nd[j] + 1])
+            for q in range(a0, a1):
+                v = float(lp[j]) - math.log(a1 - a0)
+                k = int(map_nodes[q])
+                acc[k] = v if k not in acc else float(np.logaddexp(acc[k], v))
+        items = sorted(acc.items(), key=lambda kv: (-kv[1], kv[0]))[:max_active_nodes]
+        out_nodes.extend(k for k, _ in items)
+        out_lp.extend(v for _, v in items)
+        out_off.append(len(out_nodes))
+    return (np.array(out_off, dtype=np.uint64), np.array(out_nodes, dtype=np.uint32), np.array(out_lp, dtype=np.float64))

@@ -353,3 +353,37 @@ def test_full_size_properties_cfg3(gpu_lib):
     # a second call groups the reads differently (warm-up hints) and must return the same bits
     mp2, nf2 = gm.generate_mappings(rc, None, True)
     assert all(np.array_equal(x, y) for x, y in zip(mp.arrays(), mp2.arrays())) and np.array_equal(nf, nf2)
+
+
+def test_mappings_map_nodes_matches_oracle(gpu_lib, oracle):
+    """Mapping::map_nodes (hint.rs:60-88): identity map, the parents map of hint_kp1_from_hint_k
+    (multi_dbg.rs:1325-1335) and a purge-style map with dropped nodes (multi_dbg.rs:1783-1793)."""
+    arrays, sg, reads, om, mp = _setup(oracle, n_reads=8, seed=11)
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    gmp = D.Mappings.from_arrays(rc, *mp)
+    N = arrays.n_nodes
+    # identity: nothing changes (up to the order of equal-probability entries)
+    ident = gmp.map_nodes(gm, np.arange(N + 1), np.arange(N))
+    a, b = ident.arrays(), mp
+    assert np.array_equal(a[0], b[0]) and np.allclose(a[2], b[2], atol=1e-12)
+    # node -> its parents (fan-out 0..3, shared images add up)
+    order = np.argsort(arrays.edge_dst, kind="stable")
+    par_off = np.concatenate([[0], np.cumsum(np.bincount(arrays.edge_dst, minlength=N))])
+    par_nodes = arrays.edge_src[order]
+    # purge: every third node disappears, the others are renumbered
+    keep = np.arange(N) % 3 != 0
+    newid = np.cumsum(keep) - 1
+    pur_off = np.concatenate([[0], np.cumsum(keep.astype(np.int64))])
+    pur_nodes = newid[keep]
+    for mo, mn in ((par_off, par_nodes), (pur_off, pur_nodes)):
+        got = gmp.map_nodes(gm, mo, mn).arrays()
+        exp = oracle.map_nodes(mp, mo, mn)
+        assert np.array_equal(got[0], exp[0])
+        g = 0
+        for i in range(len(exp[0]) - 1):
+            s0, s1 = int(exp[0][i]), int(exp[0][i + 1])
+            assert np.max(np.abs(got[2][s0:s1] - exp[2][s0:s1]), initial=0.0) < 1e-9
+            assert sorted(got[1][s0:s1].tolist()) == sorted(exp[1][s0:s1].tolist())
+    with pytest.raises(D.PhmmError):
+        gmp.map_nodes(gm, np.arange(N + 1), np.full(N, N + 7))
