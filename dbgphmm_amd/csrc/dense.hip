@@ -31,6 +31,9 @@
 
 #include "dense_internal.h"
 
+#ifndef PHMM_FWD_PF
+#define PHMM_FWD_PF 2
+#endif
 #ifndef PHMM_BWD_PF
 #define PHMM_BWD_PF 1
 #endif
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
         // a load under a branch makes hipcc wait for it on the spot (s_waitcnt vmcnt(0) at the join), which
         // is what defeated the ring before.  Lanes without work compute on whatever the loads return; every
         // store and every accumulator below is predicated instead.
-        constexpr int PF = 2;
+        constexpr int PF = PHMM_FWD_PF;
         double rm[PF], ri[PF];
         const int klast = a.N - 1;
         const bool lane_on = newcol || have_prev;
@@ -198,6 +201,7 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
 #pragma unroll
           for (int u = 0; u < PF; u++) {
             const int j = j0 + u;
+            if (j >= a.npt) continue;  // (PF need not divide the run length)
             int k = kbase + j;
             if (W == 64) k = __builtin_amdgcn_readfirstlane(k);
             if (k >= a.N) continue;
