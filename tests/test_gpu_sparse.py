@@ -387,3 +387,74 @@ def test_mappings_map_nodes_matches_oracle(gpu_lib, oracle):
             assert sorted(got[1][s0:s1].tolist()) == sorted(exp[1][s0:s1].tolist())
     with pytest.raises(D.PhmmError):
         gmp.map_nodes(gm, np.arange(N + 1), np.full(N, N + 7))
+
+
+def test_edge_cases_match_oracle(gpu_lib, oracle):
+    """odd inputs through the adaptive flow: bases outside ACGT, a read far longer than the rest, a read
+    that matches nowhere, one-base reads -- and an empty read set."""
+    arrays, sg = small_dbg_model(500, 12, 0.01, seed=17, min_copy_num=1)
+    rng = np.random.default_rng(5)
+    reads = D.sample_reads(arrays, 10 ** 9, 120, seed=3, max_reads=6)
+    long_read = b"".join(D.sample_reads(arrays, 10 ** 9, 400, seed=9, max_reads=6))  # 2400 bases, chimeric
+    junk = bytes(rng.choice(list(b"ACGT"), size=90).tolist())
+    with_n = bytearray(reads[0])
+    with_n[10] = ord("N")
+    with_n[40] = ord("n")
+    reads = reads + [long_read, junk, bytes(with_n), b"A", b"G"]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    tot, lp = gm.to_full_prob_reads(rc, None, True)
+    olp = om.full_prob_reads(reads, None, True, n_threads=8)
+    junk_ix = len(reads) - 4
+    ok = np.ones(len(reads), dtype=bool)
+    ok[junk_ix] = False
+    assert np.max(np.abs(lp - olp)[ok]) < 1e-6
+    # The read that matches nowhere keeps MORE than 400 nodes inside the score ratio at every sparse position:
+    # the regime where the reference's 400-slot SparseVec overflows and whose semantics are unpinned
+    # (SURVEY 8c, DESIGN.md section 2).  GPU and oracle both drop inserts there but not the same ones; what can
+    # be asserted: the sparse scores are lower bounds of the dense one and the GPU keeps at least as much mass.
+    lfd, _, _ = gm.run_dense(D.ReadCollection([junk]), False, False)
+    assert olp[junk_ix] - 1e-6 <= lp[junk_ix] <= lfd[0] + 1e-9 and abs(lp[junk_ix] - olp[junk_ix]) < 1.0
+    keep = [r for j, r in enumerate(reads) if j != junk_ix]
+    mp, nf = gm.generate_mappings(D.ReadCollection(keep), None, True)
+    omp, onf = om.generate_mappings(keep, None, True, n_threads=8)
+    _compare_mappings(keep, mp.arrays(), omp)
+    mpj, _ = gm.generate_mappings(rc, None, True)  # with the junk read: runs, lists stay inside the ratio
+    assert np.diff(mpj.arrays()[0].astype(np.int64)).max() <= 400
+    lf, lb, nfd = gm.run_dense(D.ReadCollection(reads[-4:]))
+    olf, olb, onfd = om.run_dense_reads(reads[-4:], n_threads=8)
+    assert np.max(np.abs(lf - olf)) < TOL_LOGP and np.max(np.abs(nfd - onfd)) < 1e-8
+    # The chimeric read under the DENSE recursion is the documented limit of the scaled linear domain
+    # (DESIGN.md section 3): the placement that wins after a junction was, at the junction, thousands of nats
+    # below the then-best path -- below 2^-1022 of the column maximum it is 0 on the GPU while the reference's
+    # log-space f64 keeps it.  The GPU score is then a lower bound.  (The sparse modes drop such paths in the
+    # reference too -- 30 nats below the best -- which is why the adaptive scores above agree.)
+    lfc, _, _ = gm.run_dense(D.ReadCollection([long_read]), False, False)
+    olfc, _, _ = om.run_dense_reads([long_read], n_threads=1)
+    assert lfc[0] <= olfc[0] + 1e-9
+    # no reads: a zero total, and generate_mappings refuses (nothing to map)
+    empty = D.ReadCollection([])
+    t0, l0 = gm.to_full_prob_reads(empty, None, True)
+    assert t0 == 0.0 and l0.shape == (0,)
+    with pytest.raises(D.PhmmError):
+        gm.generate_mappings(empty, None, True)
+
+
+def test_impossible_reads_zero_error_model(gpu_lib, oracle):
+    """p = 0 parameters (PHMMParams::zero_error): a read with one wrong base has probability 0.  ln P = -inf
+    comes back as -inf, its mapping lists are empty or all -inf, the other reads are unaffected."""
+    sg = D.mock_linear()
+    arrays = sg.to_phmm(D.PHMMParams.zero_error().with_(n_warmup=2, warmup_threshold=3))
+    reads = [b"CGATC", b"CGATT", b"TTCGAT"]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    _, lp = gm.to_full_prob_reads(rc, None, True)
+    olp = om.full_prob_reads(reads, None, True, n_threads=2)
+    assert np.isneginf(lp[1]) and np.isneginf(olp[1])
+    assert np.max(np.abs(lp[[0, 2]] - olp[[0, 2]])) < 1e-9
+    mp, nf = gm.generate_mappings(rc, None, True)
+    po, nd, l2 = mp.arrays()
+    off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    bad = slice(int(po[off[1]]), int(po[off[2]]))
+    assert np.all(np.isneginf(l2[bad])) or bad.start == bad.stop
+    assert np.all(np.isfinite(nf)) and abs(nf.sum() - (len(reads[0]) + len(reads[2]))) < 1e-6
