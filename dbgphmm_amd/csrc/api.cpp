@@ -273,6 +273,11 @@ void phmm_model_destroy(phmm_model *m) {
     if (!m) return;
     for (auto &ws : m->wstream)
         if (ws) (void)hipStreamDestroy(ws);
+    for (auto &ws : m->cstream)
+        if (ws) (void)hipStreamDestroy(ws);
+    for (auto &we : m->cevent)
+        for (auto &e : we)
+            if (e) (void)hipEventDestroy(e);
     delete m;
 }
 

@@ -502,15 +502,16 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         cb += bytes;
         return o;
     };
-    const size_t o_bs = carve(sizeof(int) * lanes), o_ca = carve(sizeof(int) * lanes), o_cb = carve(sizeof(int) * lanes),
+    const size_t o_bs = carve(sizeof(int) * lanes), o_ca = carve(sizeof(int) * lanes * 2), o_cb = carve(sizeof(int) * lanes * 2),
                  o_err = carve(sizeof(uint32_t) * lanes), o_lanes = carve(sizeof(uint32_t) * std::max<size_t>(sparse_lanes.size(), 1)),
                  o_lp0 = carve(sizeof(uint64_t) * (lanes + 1)), o_gp0 = carve(sizeof(uint64_t) * (lanes + 1)),
                  o_stop = carve(sizeof(int) * lanes),
-                 o_bn = carve(sizeof(uint32_t) * (size_t)lanes * KMAX), o_bv = carve(sizeof(double) * (size_t)lanes * KMAX),
+                 o_bn = carve(sizeof(uint32_t) * (size_t)lanes * KMAX * 2), o_bv = carve(sizeof(double) * (size_t)lanes * KMAX * 2),
+                 o_an = carve(sizeof(uint32_t) * (size_t)lanes * KMAX * 2), o_av = carve(sizeof(double) * (size_t)lanes * KMAX * 2),
                  o_hand = carve(sizeof(BHandoff) * (size_t)lanes);
     ctl.reserve(cb);
     char *cp = (char *)ctl.p;
-    pbuf.reserve(2 * (size_t)mc.ngc * NW * sizeof(double));
+    pbuf.reserve(3 * (size_t)mc.ngc * NW * sizeof(double));  // Pa (two buffers, by position parity) and Pb
     unsigned long long top_before = 0;
     HIP_CHECK(hipMemcpyAsync(&top_before, sink->mp.top, sizeof(top_before), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -530,7 +531,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         a.want_map = 1;
         a.bstart = (const int *)(cp + o_bs);
         a.Pa = pbuf.as<double>();
-        a.Pb = pbuf.as<double>() + (size_t)mc.ngc * NW;
+        a.Pb = pbuf.as<double>() + 2 * (size_t)mc.ngc * NW;
         // backward scratch of the chunk must start clean (a previous attempt may have used it)
         HIP_CHECK(hipMemsetAsync(a.cmaxB, 0, sizeof(unsigned long long) * (size_t)a.ng * a.Lc * W, s));
         HIP_CHECK(hipMemsetAsync(a.pmax, 0, sizeof(unsigned long long) * (size_t)a.ng * (a.Lc + 1) * W, s));
@@ -620,12 +621,8 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.W = W;
         ma.mpool = mp;
         ma.lane_pos0 = (const uint64_t *)(cp + o_gp0);
-        ma.cntA = (int *)(cp + o_ca);
-        ma.cntB = (int *)(cp + o_cb);
-        ma.candA_node = mc.cand_node;
-        ma.candA_val = mc.cand_tot;
-        ma.candB_node = (uint32_t *)(cp + o_bn);
-        ma.candB_val = (double *)(cp + o_bv);
+        // (counters and candidate lists exist twice, by position parity: emit_dense_map of a column runs while
+        // post_collect fills the next one)
         ma.ratio_lin = mc.ratio_lin;
         ma.topk = mc.topk;
         ma.err = (uint32_t *)(cp + o_err);
@@ -633,14 +630,40 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock;
         if (mc.dense_token) dense_lock = std::unique_lock<std::mutex>(*mc.dense_token);
+        // The sort + record write of a column's lists (emit_dense_map: latency-bound, and a radix select over
+        // the column where more than 400 nodes are inside the ratio) runs on a side stream under the next
+        // columns' bwd_step; the emit-prob plane is double-buffered by position parity for that.
+        const int wi = workset_index();
+        if (!m->cstream[wi]) HIP_CHECK(hipStreamCreateWithFlags(&m->cstream[wi], hipStreamNonBlocking));
+        for (auto &e : m->cevent[wi])
+            if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hipStream_t s2 = m->cstream[wi];
+        hipEvent_t *ev_col = &m->cevent[wi][0], *ev_emit = &m->cevent[wi][2];
+        bool emitted[2] = {false, false};
         for (int pos = pos_max; pos >= 0; pos--) {
+            const int par = pos & 1;
+            a.Pa = pbuf.as<double>() + (size_t)par * mc.ngc * NW;
+            ma.d = a;
+            ma.cntA = (int *)(cp + o_ca) + (size_t)par * lanes;
+            ma.cntB = (int *)(cp + o_cb) + (size_t)par * lanes;
+            ma.candA_node = (uint32_t *)(cp + o_an) + (size_t)par * lanes * KMAX;
+            ma.candA_val = (double *)(cp + o_av) + (size_t)par * lanes * KMAX;
+            ma.candB_node = (uint32_t *)(cp + o_bn) + (size_t)par * lanes * KMAX;
+            ma.candB_val = (double *)(cp + o_bv) + (size_t)par * lanes * KMAX;
+            if (emitted[par]) HIP_CHECK(hipStreamWaitEvent(s, ev_emit[par], 0));  // plane `par` is free again
             lt.begin();
             launch_bwd_step(W, a, pos);
             lt.end();
             launch_post_collect_w(W, ma, pos);
-            hipLaunchKernelGGL(emit_dense_map, dim3(lanes, 2), dim3(BLOCK), 0, s, ma, pos);
+            HIP_CHECK(hipEventRecord(ev_col[par], s));
+            HIP_CHECK(hipStreamWaitEvent(s2, ev_col[par], 0));
+            hipLaunchKernelGGL(emit_dense_map, dim3(lanes, 2), dim3(BLOCK), 0, s2, ma, pos);
+            HIP_CHECK(hipEventRecord(ev_emit[par], s2));
+            emitted[par] = true;
             if (st_on) st.launches[1]++;
         }
+        for (int par = 0; par < 2; par++)
+            if (emitted[par]) HIP_CHECK(hipStreamWaitEvent(s, ev_emit[par], 0));
         HIP_CHECK(hipGetLastError());
         st.ms[1] += lt.total_ms();
         for (int gi = 0; gi < lanes; gi++)

@@ -195,6 +195,8 @@ struct phmm_model {
     static constexpr int MAX_WORKERS = 4;
     WorkSet wsets[MAX_WORKERS];
     hipStream_t wstream[MAX_WORKERS] = {};  // worker streams, created on first use
+    hipStream_t cstream[MAX_WORKERS] = {};  // per worker: side stream of the mapping-list kernels (mapping_flow.hip)
+    hipEvent_t cevent[MAX_WORKERS][4] = {};
     phmm::DevBuf ws_out;
     WorkSet &wset() { return wsets[phmm::workset_index()]; }
     size_t owned_table_bytes() const {
