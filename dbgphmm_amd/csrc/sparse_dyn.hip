@@ -571,7 +571,9 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         const bool st_on = W == 64;
         LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock(dense_token, std::defer_lock);
-        if (W >= 32) dense_lock.lock();  // narrow plans (deferred reads) do not load the memory system
+        // (plans of deferred reads are a handful of lanes: they neither take nor wait for the token)
+        const bool use_token = it.pc->may_defer || !by_ratio;
+        if (use_token) dense_lock.lock();
         if (!by_ratio) {
             // not adaptive (forward.rs:134-137): the first n_warmup tables are dense for every read; launch
             // min(n_warmup, Lc) completes column n_warmup-1 (its Del values) or ends the short reads
@@ -633,6 +635,21 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                                      hl[gi], Lc);
                     hl[gi] = 0;  // not part of this chunk any more
                 }
+        }
+        // hand the deferred reads over NOW: their small plan runs on the side stream under the rest of this chunk
+        if (!deferred_ids.empty()) {
+            std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan_ids(m, reads, deferred_ids), (int64_t)prm.n_warmup + 2, false, {}});
+            std::lock_guard<std::mutex> lk(mu);
+            if (single_mode && side_on) {
+                enqueue_plan(std::move(pc), side_queue);
+                if (!side_started) {
+                    side_started = true;
+                    start_side_worker();
+                }
+            } else {
+                enqueue_plan(std::move(pc), queue);
+            }
+            cv.notify_all();
         }
         std::vector<uint32_t> sparse_lanes, need400;
         for (int gi = 0; gi < lanes; gi++) {
@@ -796,7 +813,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 mc.d_logp_sparse = fa.out_logp;
                 mc.cand_node = wa.cand_node;
                 mc.cand_tot = wa.cand_tot;
-                mc.dense_token = W >= 32 ? &dense_token : nullptr;
+                mc.dense_token = use_token ? &dense_token : nullptr;
                 trace("sparse forward");
                 mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
                 trace("mapping backward total");
@@ -825,7 +842,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             mc.d_logp_sparse = (double *)(wp + o_out);
             mc.cand_node = wa.cand_node;
             mc.cand_tot = wa.cand_tot;
-                mc.dense_token = W >= 32 ? &dense_token : nullptr;
+                mc.dense_token = use_token ? &dense_token : nullptr;
             mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
         }
         for (int gi = 0; gi < lanes; gi++) {
@@ -835,20 +852,6 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             lf[rd] = hsw[gi] < hl[gi] ? slp[gi] : tlf[gi];
             new_hint[rd] = (uint16_t)std::min(hsw[gi], 65535);
         }
-        }
-        if (!deferred_ids.empty()) {
-            std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan_ids(m, reads, deferred_ids), (int64_t)prm.n_warmup + 2, false, {}});
-            std::lock_guard<std::mutex> lk(mu);
-            if (single_mode && side_on) {
-                enqueue_plan(std::move(pc), side_queue);
-                if (!side_started) {
-                    side_started = true;
-                    start_side_worker();
-                }
-            } else {
-                enqueue_plan(std::move(pc), queue);
-            }
-            cv.notify_all();
         }
     };  // run_chunk
     start_side_worker = [&]() {
