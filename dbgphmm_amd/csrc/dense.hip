@@ -63,6 +63,36 @@ __device__ __forceinline__ NodeRec load_node(const NodeRec *nodes, int k) {
     return r;
 }
 
+// ---- LDS-DMA row prefetch (fwd_step<64, true>) --------------------------------------------------------
+// global_load_lds_dwordx4: 16 bytes per lane straight into LDS (wave-uniform base in M0 + lane*16), no
+// VGPR held while the load is in flight -- the only way to keep several rows per wave in flight at 128
+// VGPRs.  Issued from inline asm so that hipcc does not count it; the matching s_waitcnt vmcnt(N) is placed
+// by hand (loads, stores and LDS-DMA retire in issue order on one counter).
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+// wait until at most n vector-memory operations of this wave are outstanding (n wave-uniform, 0..31)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define PHMM_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        PHMM_VMW(1) PHMM_VMW(2) PHMM_VMW(3) PHMM_VMW(4) PHMM_VMW(5) PHMM_VMW(6) PHMM_VMW(7) PHMM_VMW(8)
+        PHMM_VMW(9) PHMM_VMW(10) PHMM_VMW(11) PHMM_VMW(12) PHMM_VMW(13) PHMM_VMW(14) PHMM_VMW(15) PHMM_VMW(16)
+        PHMM_VMW(17) PHMM_VMW(18) PHMM_VMW(19) PHMM_VMW(20) PHMM_VMW(21) PHMM_VMW(22) PHMM_VMW(23) PHMM_VMW(24)
+        PHMM_VMW(25) PHMM_VMW(26) PHMM_VMW(27) PHMM_VMW(28) PHMM_VMW(29) PHMM_VMW(30) PHMM_VMW(31)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef PHMM_VMW
+}
+#ifndef PHMM_DMA_DEPTH
+#define PHMM_DMA_DEPTH 4
+#endif
+static constexpr int DMA_DEPTH = PHMM_DMA_DEPTH;  // rows in flight per wave
+static_assert(DMA_DEPTH - 1 + DMA_DEPTH * 3 <= 31, "vmcnt immediates");
+
 // exponent e with v * 2^-e in [0.5, 1) for v > 0 (normal); 0 for v == 0
 __device__ __forceinline__ int exp_of_bits(unsigned long long bits) {
     int be = (int)((bits >> 52) & 0x7ff);
@@ -108,9 +138,12 @@ struct OpAdd {
 // ------------------------------------------------------------------ forward step
 // Launch `pos` (0..Lc): column pos of m,i for lanes with pos < len; d of column pos-1
 // for lanes with 1 <= pos <= len; the end sum of the last column for lanes with pos == len.
-template <int W>
+template <int W, bool DMA>
 __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const int pos) {
     __shared__ double lds[(BLOCK / 64) * 64];
+    constexpr bool DMA_ = DMA && W == 64;
+    // per wave: DMA_DEPTH slots of [m row 512 B][i row 512 B]
+    __shared__ double ring[DMA_ ? (BLOCK / 64) * DMA_DEPTH * 128 : 1];
     const int g = blockIdx.y;
     const int lb = xcd_block(blockIdx.x, a.nblk8);
     constexpr int ROWS = BLOCK / W;
@@ -183,17 +216,29 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
         // a load under a branch makes hipcc wait for it on the spot (s_waitcnt vmcnt(0) at the join), which
         // is what defeated the ring before.  Lanes without work compute on whatever the loads return; every
         // store and every accumulator below is predicated instead.
-        constexpr int PF = PHMM_FWD_PF;
+        constexpr int PF = DMA_ ? DMA_DEPTH : PHMM_FWD_PF;
         double rm[PF], ri[PF];
         const int klast = a.N - 1;
         const bool lane_on = newcol || have_prev;
+        // DMA: lane l < 32 fetches reads 2l, 2l+1 of the m row, lane l >= 32 those of the i row
+        const double *dma_src = ((threadIdx.x & 63) < 32 ? pm : pi) + 2 * (threadIdx.x & 31);
+        const uint32_t ring_base =
+            DMA_ ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&ring[(threadIdx.x >> 6) * DMA_DEPTH * 128]) : 0u;
+        const double *ring_w = &ring[DMA_ ? (threadIdx.x >> 6) * DMA_DEPTH * 128 : 0];
+        // vector-memory operations a row issues besides its one DMA request: the d store of column pos-1 and the
+        // m, i stores of column pos (each skipped by the compiler's branch only when NO lane of the wave has it)
+        const int ns = (__any(have_prev && pos >= 1) ? 1 : 0) + (__any(newcol) ? 2 : 0);
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             int k0 = kbase + u < klast ? kbase + u : klast;
             if (W == 64) k0 = __builtin_amdgcn_readfirstlane(k0);
-            // (lanes without work read row 0 over and over: a cache hit instead of HBM traffic)
-            rm[u] = pm[(size_t)(lane_on ? k0 : 0) * W + r];
-            ri[u] = pi[(size_t)(lane_on ? k0 : 0) * W + r];
+            if (DMA_) {
+                glds16(dma_src + (size_t)k0 * W, ring_base + (uint32_t)u * 1024u);
+            } else {
+                // (lanes without work read row 0 over and over: a cache hit instead of HBM traffic)
+                rm[u] = pm[(size_t)(lane_on ? k0 : 0) * W + r];
+                ri[u] = pi[(size_t)(lane_on ? k0 : 0) * W + r];
+            }
         }
         NodeRec nr_next = load_node(a.nodes, W == 64 ? __builtin_amdgcn_readfirstlane(kbase < klast ? kbase : klast)
                                                      : (kbase < klast ? kbase : klast));
@@ -212,7 +257,17 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
             // own m, i (PF rows ago) -- BEFORE the next requests go out: the ring slot is then dead when the
             // new load is issued, the load lands in the same registers, and no copy (= no wait) is needed at
             // the loop's back edge.
-            const double om = rm[u] * sc, oi = ri[u] * sc;
+            double om, oi;
+            if (DMA_) {
+                // the request of this row went out PF rows ago (j0 == 0: in the prologue); everything issued
+                // since is younger: PF-1 requests and ns stores per row
+                wait_vmcnt(PF - 1 + (j0 == 0 ? u : PF) * ns);
+                om = ring_w[u * 128 + r] * sc;
+                oi = ring_w[u * 128 + 64 + r] * sc;
+            } else {
+                om = rm[u] * sc;
+                oi = ri[u] * sc;
+            }
             if (W == 64) {
                 asm volatile("" : : "s"(nr.flags), "s"(nr.emis), "v"(om), "v"(oi));
                 __builtin_amdgcn_sched_barrier(0);
@@ -223,8 +278,12 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
                 nr_next = load_node(a.nodes, kn);
                 int kp = k + PF < klast ? k + PF : klast;
                 if (W == 64) kp = __builtin_amdgcn_readfirstlane(kp);
-                rm[u] = pm[(size_t)(lane_on ? kp : 0) * W + r];
-                ri[u] = pi[(size_t)(lane_on ? kp : 0) * W + r];
+                if (DMA_) {
+                    glds16(dma_src + (size_t)kp * W, ring_base + (uint32_t)u * 1024u);
+                } else {
+                    rm[u] = pm[(size_t)(lane_on ? kp : 0) * W + r];
+                    ri[u] = pi[(size_t)(lane_on ? kp : 0) * W + r];
+                }
             }
             double mnew, inew = 0.0;
             const double pe = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
@@ -313,6 +372,7 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
           }
         }
     }
+    if (DMA_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the wave's use of LDS
     // column maximum over the nodes -> next launch's rescale (which also looks at the InsBegin value)
     const double bm = block_reduce_rows<W>(vmax, OpMax(), lds);
     if (threadIdx.x < W && newcol && lb < a.nblk)
@@ -801,7 +861,7 @@ void launch_chunk(const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
     dim3 grid(a.nblk8, a.ng), blk(BLOCK);
     Timer tf(timing), tb(timing);
     tf.start();
-    for (int pos = 0; pos <= a.Lc; pos++) hipLaunchKernelGGL(fwd_step<W>, grid, blk, 0, s, a, pos);
+    for (int pos = 0; pos <= a.Lc; pos++) hipLaunchKernelGGL((fwd_step<W, false>), grid, blk, 0, s, a, pos);
     st.ms[0] += tf.stop();
     st.launches[0] += (uint64_t)a.Lc + 1;
     hipLaunchKernelGGL(fwd_finish<W>, dim3(a.ng, a.eall ? a.Lc : 1), blk, 0, s, a);
@@ -816,7 +876,11 @@ void launch_chunk(const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
 }
 
 template <int W> static void launch_fwd_one(const DenseArgs &a, int pos) {
-    hipLaunchKernelGGL(fwd_step<W>, dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
+    static const bool dma = std::getenv("PHMM_NO_DMA") == nullptr;
+    if (W == 64 && dma && a.npt % DMA_DEPTH == 0)
+        hipLaunchKernelGGL((fwd_step<W, true>), dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
+    else
+        hipLaunchKernelGGL((fwd_step<W, false>), dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
 }
 template <int W> static void launch_fwd_fin(const DenseArgs &a) {
     hipLaunchKernelGGL(fwd_finish<W>, dim3(a.ng, a.eall ? a.Lc : 1), dim3(BLOCK), 0, current_stream(), a);
