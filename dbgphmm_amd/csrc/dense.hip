@@ -464,9 +464,13 @@ __device__ __forceinline__ void bwd_chain(const DenseArgs &a, int g, int p, doub
 // Launch `pos` (Lc-1 .. 0): column pos of m,i,d for lanes with pos < len, fused with the
 // posterior accumulation  S[pos] = F.tables[pos-1] (.) B.tables[pos] / P  (and the
 // j = L term F.tables[L-1] (.) B.init / P when pos == len-1).
-template <int W>
+static constexpr int BDMA_DEPTH = 3;      // rows in flight per wave (5 planes = 2.5 KB per row)
+static constexpr int BDMA_SLOT = 5 * 64;  // doubles per slot: [B' m][B' i][F m][F i][F d]
+template <int W, bool DMA>
 __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const int pos) {
     __shared__ double lds[(BLOCK / 64) * 64];
+    constexpr bool DMA_ = DMA && W == 64;
+    __shared__ double ring[DMA_ ? (BLOCK / 64) * BDMA_DEPTH * BDMA_SLOT : 1];
     const int g = blockIdx.y;
     const int lb = xcd_block(blockIdx.x, a.nblk8);
     constexpr int ROWS = BLOCK / W;
@@ -546,19 +550,40 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
         // lane; pointers that a launch does not use alias a valid plane) and a ring slot is consumed before
         // it is requested again, so that hipcc neither waits at a join nor copies at the back edge:
         // B values are consumed at the top of a row and re-requested there, F values at its end.
-        constexpr int PFB = PHMM_BWD_PF;
+        constexpr int PFB = DMA_ ? BDMA_DEPTH : PHMM_BWD_PF;
         double nx_m[PFB], nx_i[PFB], nx_fm[PFB], nx_fi[PFB], nx_fd[PFB];
         const double *lfm = want_post ? fm : nm, *lfi = want_post ? fi : nm, *lfd = want_post ? fd : nm;
         // rows kbase+jtop .. kbase (jtop clamps the last block of the column)
         const int jtop = a.npt - 1 < a.N - 1 - kbase ? a.npt - 1 : a.N - 1 - kbase;
+        // LDS-DMA variant (see fwd_step): three requests per row -- A: B' m | B' i, B: F m | F i, C: F d (lower
+        // half of the wave) -- into slot u of this wave's ring; A is consumed at the top of a row and requested
+        // again there, B and C at its end.  Vector-memory operations of a row besides the 3 requests: n1 stores
+        // of B (before the F values are read) and n2 of the emit-prob plane (after).
+        const int l64 = threadIdx.x & 63;
+        const double *srcA = (l64 < 32 ? nm : ni) + 2 * (l64 & 31);
+        const double *srcB = (l64 < 32 ? lfm : lfi) + 2 * (l64 & 31);
+        const double *srcC = lfd + 2 * (l64 & 31);
+        const uint32_t ring_base =
+            DMA_ ? (uint32_t)__builtin_amdgcn_readfirstlane(
+                       (int)(uint32_t)(uintptr_t)&ring[(threadIdx.x >> 6) * BDMA_DEPTH * BDMA_SLOT])
+                 : 0u;
+        const double *ring_w = &ring[DMA_ ? (threadIdx.x >> 6) * BDMA_DEPTH * BDMA_SLOT : 0];
+        const int n1 = __any(live) ? 2 + (od ? 1 : 0) : 0;
+        const int ns = n1 + ((a.want_map && __any(live)) ? 1 : 0) + (a.want_freq ? 2 : 0);
 #pragma unroll
         for (int u = 0; u < PFB; u++) {
             int v0 = kbase + (jtop - u > 0 ? jtop - u : 0);
+            if (v0 > a.N - 1) v0 = a.N - 1;  // (a run past the end of the column: nothing is consumed)
             if (W == 64) v0 = __builtin_amdgcn_readfirstlane(v0);
             // (lanes that are not live read row 0 over and over: a cache hit instead of HBM traffic)
             const size_t i0 = (size_t)(live ? v0 : 0) * W + r;
             nx_m[u] = nx_i[u] = nx_fm[u] = nx_fi[u] = nx_fd[u] = 0.0;
-            if (jtop >= 0) {
+            if (DMA_) {
+                const uint32_t slot = ring_base + (uint32_t)u * (BDMA_SLOT * 8);
+                glds16(srcA + (size_t)v0 * W, slot);
+                glds16(srcB + (size_t)v0 * W, slot + 1024u);
+                if (l64 < 32) glds16(srcC + (size_t)v0 * W, slot + 2048u);
+            } else if (jtop >= 0) {
                 nx_m[u] = nm[i0];
                 nx_i[u] = ni[i0];
                 nx_fm[u] = lfm[i0];
@@ -583,21 +608,35 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
             {
                 const NodeRec nr = nr_next;
                 const size_t iv = (size_t)v * W + r;
-                const double cur_m = nx_m[u] * sc, cur_i = nx_i[u] * sc;
+                const bool first_group = j0 == jtop;
+                double cur_m, cur_i;
+                if (DMA_) {
+                    // younger than request A of this row: its B and C, then per row since 3 requests + ns others
+                    wait_vmcnt(2 + 3 * (PFB - 1) + (first_group ? u : PFB) * ns);
+                    cur_m = ring_w[u * BDMA_SLOT + r] * sc;
+                    cur_i = ring_w[u * BDMA_SLOT + 64 + r] * sc;
+                } else {
+                    cur_m = nx_m[u] * sc;
+                    cur_i = nx_i[u] * sc;
+                }
                 if (W == 64) {
                     asm volatile("" : : "s"(nr.flags), "s"(nr.emis), "v"(cur_m), "v"(cur_i));
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                int vp = v - PFB > kbase ? v - PFB : kbase;
+                if (W == 64) vp = __builtin_amdgcn_readfirstlane(vp);
                 {
                     int vn = v - 1 > kbase ? v - 1 : kbase;
                     if (W == 64) vn = __builtin_amdgcn_readfirstlane(vn);
                     nr_next = load_node(a.nodes, vn);
-                    int vp = v - PFB > kbase ? v - PFB : kbase;
-                    if (W == 64) vp = __builtin_amdgcn_readfirstlane(vp);
-                    nx_m[u] = nm[(size_t)(live ? vp : 0) * W + r];
-                    nx_i[u] = ni[(size_t)(live ? vp : 0) * W + r];
+                    if (DMA_) {
+                        glds16(srcA + (size_t)vp * W, ring_base + (uint32_t)u * (BDMA_SLOT * 8));
+                    } else {
+                        nx_m[u] = nm[(size_t)(live ? vp : 0) * W + r];
+                        nx_i[u] = ni[(size_t)(live ? vp : 0) * W + r];
+                    }
                 }
-                const double cur_fm = nx_fm[u], cur_fi = nx_fi[u], cur_fd = nx_fd[u];
+                double cur_fm = nx_fm[u], cur_fi = nx_fi[u], cur_fd = nx_fd[u];
                 const double m0 = first ? lp.p_end : cur_m;
                 const double q0 = lp.p_random * (first ? lp.p_end : cur_i);
                 const double ev = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
@@ -672,18 +711,18 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
                     s1 += in * (lp.p_MM * ev * m0 + lp.p_MD * d);
                     s2 += in * (lp.p_IM * ev * m0 + lp.p_ID * d);
                 }
+                if (DMA_) {
+                    // younger than request C of this row: per row since 3 requests + ns others, plus request A
+                    // and the n1 stores of this row
+                    wait_vmcnt(1 + n1 + 3 * (PFB - 1) + (first_group ? (u < PFB - 1 ? u : PFB - 1) : PFB - 1) * ns);
+                    cur_fm = ring_w[u * BDMA_SLOT + 128 + r];
+                    cur_fi = ring_w[u * BDMA_SLOT + 192 + r];
+                    cur_fd = ring_w[u * BDMA_SLOT + 256 + r];
+                }
                 double c1 = 0.0, c2 = 0.0;
                 if (wgt != 0.0) c1 = wgt * (cur_fm * m + cur_fi * i + cur_fd * d);
                 if (wgt2 != 0.0) c2 = wgt2 * (gm[iv] + gi[iv] + gd[iv]);
                 contrib = c1 + c2;
-                {
-                    // this slot's F values are spent: request the row PFB below
-                    int vp = v - PFB > kbase ? v - PFB : kbase;
-                    if (W == 64) vp = __builtin_amdgcn_readfirstlane(vp);
-                    nx_fm[u] = lfm[(size_t)(live ? vp : 0) * W + r];
-                    nx_fi[u] = lfi[(size_t)(live ? vp : 0) * W + r];
-                    nx_fd[u] = lfd[(size_t)(live ? vp : 0) * W + r];
-                }
                 if (a.want_map && live) {
                     // emit probs of merged index pos (and of merged index len when `first`):
                     // kept for post_collect (to_mapping_by_score_ratio, hint.rs:135-142)
@@ -694,6 +733,22 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
                         pmx2 = fmax(pmx2, c2);
                     }
                 }
+                {
+                    // this slot's F values are spent: request the row PFB below
+                    if (DMA_) {
+                        if (W == 64) {
+                            asm volatile("" : : "v"(contrib));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        const uint32_t slot = ring_base + (uint32_t)u * (BDMA_SLOT * 8);
+                        glds16(srcB + (size_t)vp * W, slot + 1024u);
+                        if (l64 < 32) glds16(srcC + (size_t)vp * W, slot + 2048u);
+                    } else {
+                        nx_fm[u] = lfm[(size_t)(live ? vp : 0) * W + r];
+                        nx_fi[u] = lfi[(size_t)(live ? vp : 0) * W + r];
+                        nx_fd[u] = lfd[(size_t)(live ? vp : 0) * W + r];
+                    }
+                }
             }
             if (a.want_freq) {
                 const double tot = lanes_sum<W>(contrib);
@@ -702,6 +757,7 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
           }
         }
     }
+    if (DMA_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the wave's use of LDS
     const double bmx = block_reduce_rows<W>(vmax, OpMax(), lds);
     if (threadIdx.x < W && live && lb < a.nblk)
         atomicMax(&a.cmaxB[((size_t)g * a.Lc + pos) * W + r], (unsigned long long)__double_as_longlong(bmx));
@@ -867,7 +923,7 @@ void launch_chunk(const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
     hipLaunchKernelGGL(fwd_finish<W>, dim3(a.ng, a.eall ? a.Lc : 1), blk, 0, s, a);
     if (do_bwd) {
         tb.start();
-        for (int pos = a.Lc - 1; pos >= 0; pos--) hipLaunchKernelGGL(bwd_step<W>, grid, blk, 0, s, a, pos);
+        for (int pos = a.Lc - 1; pos >= 0; pos--) hipLaunchKernelGGL((bwd_step<W, false>), grid, blk, 0, s, a, pos);
         st.ms[1] += tb.stop();
         st.launches[1] += (uint64_t)a.Lc;
         hipLaunchKernelGGL(bwd_finish<W>, dim3(a.ng), blk, 0, s, a);
@@ -902,7 +958,13 @@ void launch_fwd_step(int W, const DenseArgs &a, int pos) {
 #undef CALL_
 }
 template <int W> static void launch_bwd_one(const DenseArgs &a, int pos) {
-    hipLaunchKernelGGL(bwd_step<W>, dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
+    // The LDS-DMA variant of the backward (5 planes per row, 3 requests) measured 6 % SLOWER than the register
+    // ring on cfg3 (6.35 vs 5.96 ms per launch): opt-in only (PHMM_BWD_DMA=1), kept for the next round.
+    static const bool dma = std::getenv("PHMM_BWD_DMA") != nullptr;
+    if (W == 64 && dma)
+        hipLaunchKernelGGL((bwd_step<W, true>), dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
+    else
+        hipLaunchKernelGGL((bwd_step<W, false>), dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
 }
 void launch_bwd_step(int W, const DenseArgs &a, int pos) {
 #define CALL_(w) launch_bwd_one<w>(a, pos)
