@@ -105,7 +105,7 @@ def pmc_traffic(kernel: str):
     path = os.environ.get("PHMM_PMC_SUMMARY", os.path.join(ROOT, "profiles", "r1_cfg3_pmc_traffic.json"))
     try:
         doc = json.load(open(path))
-        k = doc["kernels"][kernel]
+        k = next(v for name, v in doc["kernels"].items() if name.startswith(kernel))
         return float(k["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
     except Exception:
         return None, None
@@ -233,7 +233,7 @@ def main():
         # dominant kernel: bwd_step (backward column + fused F(.)B posterior): B write 24 + B prev read 24 +
         # F re-read 24 = 72 algorithmic bytes per cell; fwd_step: 24 + 24 = 48.
         rb, rf = roof(1, 72.0), roof(0, 48.0)
-        traffic, traffic_src = pmc_traffic("phmm::bwd_step<64>") if args.workload == "cfg3" else (None, None)
+        traffic, traffic_src = pmc_traffic("phmm::bwd_step<64") if args.workload == "cfg3" else (None, None)
         out = {
             "metric": "read-bases/sec through forward+backward P(R|X)",
             "value": total_bases * args.steps / dt,
