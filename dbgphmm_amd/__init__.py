@@ -9,3 +9,5 @@ from .graph import (PHMMArrays, SeqGraph, mock_linear, mock_crossing, toy_repeat
                     dbg_from_haplotypes, random_genome, diverge, sample_reads, vectorised_to_phmm)
 from .model import PHMMModel, PHMMOutput, ReadCollection, Mappings, DenseTables  # noqa: F401
 from ._ffi import PhmmError, build  # noqa: F401
+
+from . import formats  # noqa: F401,E402  (DBG / MAP / FASTA files either side of the path)

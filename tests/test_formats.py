@@ -1,0 +1,90 @@
+"""Host-side file formats either side of the path (dbgphmm_amd/formats.py): the reference's own tests for these
+are dump/load round trips (multi_dbg/output.rs:846-905); the grammar is the one documented there."""
+import numpy as np
+import pytest
+
+import dbgphmm_amd as D
+from dbgphmm_amd import formats as F
+from dbgphmm_amd.graph import NULL_BASE
+
+
+def _kmers_first_occurrence(haps, k):
+    pad = bytes([NULL_BASE]) * (k - 1)
+    order, count = [], {}
+    for h in haps:
+        a = pad + bytes(h) + pad
+        for i in range(len(a) - k + 1):
+            km = a[i:i + k]
+            if km not in count:
+                count[km] = 0
+                order.append(km)
+            count[km] += 1
+    return order, [count[km] for km in order]
+
+
+def _same_graph(a: D.SeqGraph, b: D.SeqGraph):
+    assert np.array_equal(a.copy_num, b.copy_num) and np.array_equal(a.base, b.base)
+    ea = sorted(zip(a.edge_src.tolist(), a.edge_dst.tolist()))
+    eb = sorted(zip(b.edge_src.tolist(), b.edge_dst.tolist()))
+    assert ea == eb
+
+
+def test_fasta_roundtrip(tmp_path):
+    reads = [b"ACGTACGT", b"TTGACA", b"G"]
+    p = str(tmp_path / "reads.fa")
+    F.write_fasta(p, reads)
+    assert F.read_fasta(p) == reads
+    (tmp_path / "lower.fa").write_text(">x\nacgt\nAC\n>y\nGG\n")
+    assert F.read_fasta(str(tmp_path / "lower.fa")) == [b"ACGTAC", b"GG"]  # multi-line records, case folded
+    (tmp_path / "bad.fa").write_text(">x\nACNT\n")
+    with pytest.raises(ValueError):  # collection.rs:236-249 panics on a non-DNA base
+        F.read_fasta(str(tmp_path / "bad.fa"))
+
+
+@pytest.mark.parametrize("name", ["m.map", "m.mpz", "m.map.gz"])
+def test_map_roundtrip(tmp_path, name):
+    reads = [b"GATCC", b"TATCA", b"A"]
+    rng = np.random.default_rng(0)
+    cnt = rng.integers(0, 4, size=sum(map(len, reads)))
+    po = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+    nd = rng.integers(0, 50, size=int(po[-1])).astype(np.uint32)
+    lp = -rng.random(int(po[-1])) * 30
+    lp[:2] = [-np.inf, -1e-300] if po[-1] >= 2 else lp[:2]
+    p = str(tmp_path / name)
+    F.write_map(p, reads, (po, nd, lp), k=4, n_edges_full=50, n_edges_compact=7)
+    r2, (po2, nd2, lp2) = F.read_map(p)
+    assert r2 == reads and np.array_equal(po, po2) and np.array_equal(nd, nd2)
+    assert np.array_equal(lp, lp2)  # repr() round-trips f64 exactly, -inf included
+    text = open(p, "rb").read()
+    assert (text[:2] == b"\x1f\x8b") == name.endswith(("z",))  # .mpz / .gz are gzip (output.rs:476-480)
+
+
+def test_dbg_unitig_file_gives_the_kmer_graph():
+    """one unitig from the terminal node back to it (k = 4, genome ATCGGA): 9 full edges, no PHMM edge through nnn"""
+    text = "# example\nK\t4\nN\t0\tnnn\nE\t0\t0\t0\tnnnATCGGAnnn\t1\t0,1,2,3,4,5,6,7,8\n"
+    dbg = F.read_dbg(text, is_text=True)
+    assert dbg.k == 4 and dbg.n_edges_full == 9
+    _same_graph(dbg.to_seq_graph(), D.dbg_from_haplotypes([np.frombuffer(b"ATCGGA", dtype=np.uint8)], 4))
+    with pytest.raises(ValueError):
+        F.read_dbg("K\t4\nN\t0\tnnn\nE\t0\t0\t0\tnnnATC\t1\t0,1\n", is_text=True).to_seq_graph()
+
+
+@pytest.mark.parametrize("seed,k", [(1, 8), (2, 12)])
+def test_dbg_roundtrip_matches_builder(tmp_path, seed, k):
+    hap = D.random_genome(300, seed=seed)
+    haps = [hap, D.diverge(hap, 0.03, seed=seed + 1)]
+    kmers, cns = _kmers_first_occurrence(haps, k)
+    dbg = F.dbg_from_seq_graph_kmers(kmers, cns, k)
+    p = str(tmp_path / "g.dbg.gz")
+    F.write_dbg(p, dbg)
+    back = F.read_dbg(p)
+    assert back.k == k and back.km1mers == dbg.km1mers and back.edges == dbg.edges
+    sg = back.to_seq_graph()
+    _same_graph(sg, D.dbg_from_haplotypes(haps, k))
+    # and the PHMM of the two is the same model (edge order aside)
+    a = D.vectorised_to_phmm(sg, D.PHMMParams.uniform(0.01), 1)
+    b = D.vectorised_to_phmm(D.dbg_from_haplotypes(haps, k), D.PHMMParams.uniform(0.01), 1)
+    assert np.array_equal(a.init_logp, b.init_logp)
+    ta = sorted(zip(a.edge_src.tolist(), a.edge_dst.tolist(), a.trans_logp.tolist()))
+    tb = sorted(zip(b.edge_src.tolist(), b.edge_dst.tolist(), b.trans_logp.tolist()))
+    assert ta == tb

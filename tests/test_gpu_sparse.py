@@ -458,3 +458,34 @@ def test_impossible_reads_zero_error_model(gpu_lib, oracle):
     bad = slice(int(po[off[1]]), int(po[off[2]]))
     assert np.all(np.isneginf(l2[bad])) or bad.start == bad.stop
     assert np.all(np.isfinite(nf)) and abs(nf.sum() - (len(reads[0]) + len(reads[2]))) < 1e-6
+
+
+def test_files_to_likelihood_end_to_end(gpu_lib, oracle, tmp_path):
+    """what the reference's `infer` resumes from (bin/infer.rs:47-48, 90-94): DBG + MAP + FASTA files -> model,
+    reads, mappings -> hinted read-set likelihood; equal to the in-memory path bit for bit."""
+    from dbgphmm_amd import formats as F
+    from test_formats import _kmers_first_occurrence
+    k = 12
+    hap = D.random_genome(400, seed=4)
+    haps = [hap, D.diverge(hap, 0.02, seed=5)]
+    sg = D.dbg_from_haplotypes(haps, k)
+    param = D.PHMMParams.uniform(0.01).with_(n_warmup=k)
+    arrays = D.vectorised_to_phmm(sg, param, 1)
+    reads = D.sample_reads(arrays, 10 ** 9, 100, seed=2, max_reads=10)
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    mp, _ = gm.generate_mappings(rc, None, True)
+    tot0, lp0 = gm.to_full_prob_reads(rc, mp)
+    kmers, cns = _kmers_first_occurrence(haps, k)
+    F.write_dbg(str(tmp_path / "g.dbg"), F.dbg_from_seq_graph_kmers(kmers, cns, k))
+    F.write_map(str(tmp_path / "m.mpz"), reads, mp.arrays(), k=k, n_edges_full=arrays.n_nodes)
+    F.write_fasta(str(tmp_path / "r.fa"), reads)
+    sg2 = F.read_dbg(str(tmp_path / "g.dbg")).to_seq_graph()
+    reads2 = F.read_fasta(str(tmp_path / "r.fa"))
+    _, arrs = F.read_map(str(tmp_path / "m.mpz"))
+    gm2 = D.PHMMModel(D.vectorised_to_phmm(sg2, param, 1))
+    rc2 = D.ReadCollection(reads2)
+    tot1, lp1 = gm2.to_full_prob_reads(rc2, D.Mappings.from_arrays(rc2, *arrs))
+    assert reads2 == reads and np.max(np.abs(lp1 - lp0)) < 1e-12
+    olp = oracle.Model(D.vectorised_to_phmm(sg2, param, 1)).full_prob_reads(reads2, arrs, True, n_threads=4)
+    assert np.max(np.abs(lp1 - olp)) < TOL_LOGP
