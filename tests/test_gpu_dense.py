@@ -176,3 +176,27 @@ def test_edge_and_init_freqs_match_oracle(gpu_lib, oracle, n_reads):
     # every read leaves the Begin states about once (the forward `e` and the backward b_init treat a
     # trailing deletion differently, as for the node posteriors above)
     assert abs(nf.sum() - len(reads)) < 0.01 * len(reads)
+
+
+@pytest.mark.parametrize("gaps", [0, 1, 2, 4, 5, 6])
+def test_n_max_gaps_variants_match_oracle(gpu_lib, oracle, gaps):
+    """n_max_gaps != 4: up to 4 the per-hop window with masked coefficients, above it merged closure entries
+    (dense.hip); the frontier kernels loop over the Del levels.  Dense, adaptive and hinted scores vs the oracle."""
+    arrays, _ = small_dbg_model(400, 12, 0.01, seed=31, min_copy_num=1)
+    arrays.param = arrays.param.with_(n_max_gaps=gaps)
+    reads = D.sample_reads(arrays, 10 ** 9, 90, seed=7, max_reads=9)
+    reads = [r[: max(1, len(r) - (j * 7) % 31)] for j, r in enumerate(reads)]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    lf, lb, nf = gm.run_dense(rc)
+    olf, olb, onf = om.run_dense_reads(reads, n_threads=8)
+    assert np.max(np.abs(lf - olf)) < TOL_LOGP and np.max(np.abs(lb - olb)) < TOL_LOGP
+    assert np.max(np.abs(nf - onf)) < TOL_FREQ * len(reads)
+    _, lp = gm.to_full_prob_reads(rc, None, True)
+    olp = om.full_prob_reads(reads, None, True, n_threads=8)
+    assert np.max(np.abs(lp - olp)) < 1e-6
+    mp, _ = gm.generate_mappings(rc, None, True)
+    omp, _ = om.generate_mappings(reads, None, True, n_threads=8)
+    _, lh = gm.to_full_prob_reads(rc, mp)
+    olh = om.full_prob_reads(reads, omp, True, n_threads=8)
+    assert np.max(np.abs(lh - olh)) < 1e-6
