@@ -334,6 +334,27 @@ int phmm_run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf,
     });
 }
 
+int phmm_q_score_exact(const phmm_model *m, const double *edge_freq, const double *init_freq, double *out_q) {
+    return guarded([&] {
+        if (!m || !init_freq || !out_q || (m->E && !edge_freq)) PHMM_THROW(PHMM_EINVAL, "NULL argument");
+        double init = 0.0, trans = 0.0;
+        for (uint32_t v = 0; v < m->N; v++) {
+            if (m->emission[v] == (uint8_t)'n') continue;
+            if (!std::isfinite(m->init_logp[v])) PHMM_THROW(PHMM_EINVAL, "init_prob of an emittable node is not finite (q.rs:79)");
+            init += init_freq[v] * m->init_logp[v];
+            for (uint32_t a = m->chi_off[v]; a < m->chi_off[v + 1]; a++) {
+                if (m->emission[m->chi_node[a]] == (uint8_t)'n') continue;
+                const uint32_t e = m->chi_edge[a];
+                if (!std::isfinite(m->trans_logp[e])) PHMM_THROW(PHMM_EINVAL, "trans_prob between emittable nodes is not finite (q.rs:88)");
+                trans += edge_freq[e] * m->trans_logp[e];
+            }
+        }
+        out_q[0] = init;
+        out_q[1] = trans;
+        out_q[2] = 0.0;
+    });
+}
+
 int phmm_dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i, double *f_d,
                       double *f_scal, double *b_m, double *b_i, double *b_d, double *b_scal) {
     return guarded([&] {

@@ -235,6 +235,16 @@ class PHMMModel:
         _ffi.check(_ffi.lib().phmm_run_dense_edges(self._h, reads._h, _ptr(lf), _ptr(ef), _ptr(nf)))
         return lf, ef[:self.n_edges], nf
 
+    def q_score_exact(self, edge_freqs: np.ndarray, init_freqs: np.ndarray):
+        """q_score_exact (src/hmmv2/q.rs:66-96) -> (init, trans, prior); QScore::total() is their sum."""
+        ef = np.ascontiguousarray(edge_freqs, dtype=np.float64)
+        nf = np.ascontiguousarray(init_freqs, dtype=np.float64)
+        if ef.size < self.n_edges or nf.size < self.n_nodes:
+            raise ValueError("edge_freqs / init_freqs shorter than the model")
+        q = np.empty(3)
+        _ffi.check(_ffi.lib().phmm_q_score_exact(self._h, _ptr(ef) if self.n_edges else None, _ptr(nf), _ptr(q)))
+        return float(q[0]), float(q[1]), float(q[2])
+
     def to_full_prob_reads_copy_nums(self, reads: ReadCollection, mappings: Mappings, copy_nums: np.ndarray,
                                      min_copy_num: int = 0):
         """The same loop with candidates given as copy-number vectors [C,N] (what the sampler varies,

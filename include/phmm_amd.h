@@ -120,6 +120,16 @@ int phmm_run_dense(phmm_model *m, const phmm_reads *reads, double *out_logp_forw
 int phmm_run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_logp_forward,
                          double *out_edge_freq, double *out_init_freq);
 
+/* Q function of an EM step from those posteriors: q_score_exact (src/hmmv2/q.rs:66-96).
+ *   out_q[0] = init  = sum over emittable v of init_freq[v] * ln init_prob(v)
+ *   out_q[1] = trans = sum over edges v -> w between emittable nodes of edge_freq[e] * ln trans_prob(e)
+ *   out_q[2] = prior = 0 (q.rs:94-95);  QScore::total() is the sum of the three (q.rs:30-36).
+ * Folded in the reference's order (nodes by id, the children of a node newest edge first).  A -inf
+ * init / trans probability on that walk is PHMM_EINVAL (the reference asserts is_finite, q.rs:79, 88).
+ * Host pointers; O(N + E) on the host from the probabilities the model was created / last set with. */
+int phmm_q_score_exact(const phmm_model *m, const double *edge_freq, const double *init_freq,
+                       double *out_q);
+
 /* Dense tables of ONE read for parity tests / `inspect`-style tools:
  * PHMMModel::forward / backward (forward.rs:24-45; backward.rs:24-53).
  * f_m/f_i/f_d: [L][N] natural-log values of F.tables[i]; f_scal: [L][3] = mb, ib, e.

@@ -178,6 +178,35 @@ def test_edge_and_init_freqs_match_oracle(gpu_lib, oracle, n_reads):
     assert abs(nf.sum() - len(reads)) < 0.01 * len(reads)
 
 
+def test_q_score_exact(gpu_lib, oracle):
+    """q_score_exact (q.rs:66-96): init = sum init_freq * ln init, trans = sum edge_freq * ln trans over emittable
+    nodes / edges between emittable nodes, prior = 0.  The reference holds no KAT for it: the expected value is the
+    formula evaluated on the ORACLE's transition posteriors."""
+    arrays, _ = small_dbg_model(300, 12, 0.01, seed=5, min_copy_num=1)
+    reads = D.sample_reads(arrays, 10 ** 9, 60, seed=3, max_reads=20)
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    _, ef, nf = gm.run_dense_edge_freqs(D.ReadCollection(reads))
+    oef, onf = np.zeros(arrays.n_edges), np.zeros(arrays.n_nodes)
+    for r in reads:
+        e1, n1 = om.run(r).to_edge_and_init_freqs()
+        oef += e1
+        onf += n1
+    emit = arrays.emission != ord("n")
+    ok_e = emit[arrays.edge_src] & emit[arrays.edge_dst]
+    want_init = float(np.sum(onf[emit] * arrays.init_logp[emit]))
+    want_trans = float(np.sum(oef[ok_e] * arrays.trans_logp[ok_e]))
+    qi, qt, qp = gm.q_score_exact(ef, nf)
+    assert qp == 0.0
+    assert abs(qi - want_init) < 1e-6 * max(1.0, abs(want_init))
+    assert abs(qt - want_trans) < 1e-6 * max(1.0, abs(want_trans))
+    assert qi < 0 and qt <= 0
+    # a zero-probability node on the walk is the reference's assert (q.rs:79)
+    a0, _ = small_dbg_model(300, 12, 0.01, seed=5, min_copy_num=0)
+    if np.any(np.isinf(a0.init_logp[a0.emission != ord("n")])):
+        with pytest.raises(D.PhmmError):
+            D.PHMMModel(a0).q_score_exact(ef, nf)
+
+
 @pytest.mark.parametrize("gaps", [0, 1, 2, 4, 5, 6])
 def test_n_max_gaps_variants_match_oracle(gpu_lib, oracle, gaps):
     """n_max_gaps != 4: up to 4 the per-hop window with masked coefficients, above it merged closure entries
