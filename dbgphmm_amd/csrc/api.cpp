@@ -334,6 +334,29 @@ int phmm_run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf,
     });
 }
 
+int phmm_full_prob_sparse_backward(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total) {
+    return guarded([&] {
+        if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
+        if (reads->R == 0) {
+            const double zero = 0.0;  // empty product = Prob::one()
+            put_doubles(out_total, &zero, 1);
+            return;
+        }
+        for (uint64_t r = 0; r < reads->R; r++)
+            if (reads->off[r + 1] == reads->off[r]) PHMM_THROW(PHMM_EINVAL, "empty read (reference panics: table.rs:388)");
+        full_prob_sparse_backward(m, reads, out_logp, out_total);
+    });
+}
+
+int phmm_backward_sparse_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *b_m, double *b_i, double *b_d,
+                                double *b_scal, uint8_t *is_dense) {
+    return guarded([&] {
+        if (!m || !read) PHMM_THROW(PHMM_EINVAL, "NULL model or read");
+        if (len == 0) PHMM_THROW(PHMM_EINVAL, "empty read");
+        backward_sparse_tables(m, read, len, b_m, b_i, b_d, b_scal, is_dense);
+    });
+}
+
 int phmm_q_score_exact(const phmm_model *m, const double *edge_freq, const double *init_freq, double *out_q) {
     return guarded([&] {
         if (!m || !init_freq || !out_q || (m->E && !edge_freq)) PHMM_THROW(PHMM_EINVAL, "NULL argument");

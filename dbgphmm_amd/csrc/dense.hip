@@ -971,6 +971,15 @@ void launch_bwd_step(int W, const DenseArgs &a, int pos) {
     PHMM_W_SWITCH(W, CALL_)
 #undef CALL_
 }
+template <int W> static void launch_bwd_fin(const DenseArgs &a) {
+    hipLaunchKernelGGL(bwd_finish<W>, dim3(a.ng), dim3(BLOCK), 0, current_stream(), a);
+}
+void launch_bwd_finish(int W, const DenseArgs &a) {
+#define CALL_(w) launch_bwd_fin<w>(a)
+    PHMM_W_SWITCH(W, CALL_)
+#undef CALL_
+    HIP_CHECK(hipGetLastError());
+}
 void launch_fwd_finish(int W, const DenseArgs &a) {
 #define CALL_(w) launch_fwd_fin<w>(a)
     PHMM_W_SWITCH(W, CALL_)
@@ -1055,16 +1064,18 @@ Plan make_plan_ids(const phmm_model *m, const phmm_reads *reads, const std::vect
 }
 
 // lay out one chunk (ngc groups, Lc columns); pass null bases to measure
-void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &tb, size_t &mb) {
+void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &tb, size_t &mb, bool backward_only) {
     const size_t NW = (size_t)a.N * W;
     Carver t(tables), s(misc);
-    a.Fm = t.take<double>((size_t)a.ng * a.Lc * NW);
-    a.Fi = t.take<double>((size_t)a.ng * a.Lc * NW);
-    a.Fd = t.take<double>((size_t)a.ng * a.Lc * NW);
+    // backward_only (backward_sparse's dense tail, sparse_bwd.hip): no forward tables, Del kept in the ping-pong
+    const size_t fcols = backward_only ? 0 : (size_t)a.Lc;
+    a.Fm = t.take<double>((size_t)a.ng * fcols * NW);
+    a.Fi = t.take<double>((size_t)a.ng * fcols * NW);
+    a.Fd = t.take<double>((size_t)a.ng * fcols * NW);
     a.bcols = full_b ? a.Lc : 2;
     a.Bm = t.take<double>((size_t)a.ng * a.bcols * NW);
     a.Bi = t.take<double>((size_t)a.ng * a.bcols * NW);
-    a.Bd = full_b ? t.take<double>((size_t)a.ng * a.bcols * NW) : nullptr;
+    a.Bd = (full_b || backward_only) ? t.take<double>((size_t)a.ng * a.bcols * NW) : nullptr;
     tb = t.off;
     a.bases = s.take<uint8_t>((size_t)a.ng * a.Lc * W);
     a.len = s.take<int>((size_t)a.ng * W);

@@ -78,11 +78,13 @@ struct Plan {
 
 Plan make_plan(const phmm_model *m, const phmm_reads *reads, int forced_w);
 Plan make_plan_ids(const phmm_model *m, const phmm_reads *reads, const std::vector<uint32_t> &ids);
-void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &tb, size_t &mb);
+void layout(DenseArgs &a, int W, bool full_b, void *tables, void *misc, size_t &tb, size_t &mb,
+            bool backward_only = false);
 void fill_model_args(DenseArgs &a, const phmm_model *m);
 void host_logib(const phmm_model *m, size_t n, std::vector<double> &out);
 void launch_fwd_step(int W, const DenseArgs &a, int pos);
 void launch_fwd_finish(int W, const DenseArgs &a);
 void launch_bwd_step(int W, const DenseArgs &a, int pos);
+void launch_bwd_finish(int W, const DenseArgs &a);
 
 }  // namespace phmm

@@ -290,6 +290,10 @@ void model_upload(phmm_model *m);        // closures + device arrays
 // dense driver (dense.hip)
 void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb,
                double *out_nf);
+// backward_sparse (backward.rs:146-185): sparse_bwd.hip
+void full_prob_sparse_backward(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total);
+void backward_sparse_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *b_m, double *b_i, double *b_d,
+                            double *b_scal, uint8_t *is_dense);
 void run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_ef, double *out_if);
 struct RecPool;
 // sparse / hinted drivers (sparse.hip)

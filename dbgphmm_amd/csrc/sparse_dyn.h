@@ -179,6 +179,24 @@ struct MapChunk {
     std::mutex *dense_token;  // held while the chunk runs its HBM-bound dense backward (sparse_dyn.hip)
 };
 
+// top_nodes(K) / the 400 best of a dense column (sparse_dyn.hip: select_top400).  The column is read through
+// d.Fm/Fi/Fd at column sw[lane]-1 of a [ng][d.Lc][N][W] table; d.tmaxF bounds its totals from above.
+struct Top400Args {
+    DenseArgs d;
+    int W;
+    const int *sw;
+    const uint32_t *need;  // lanes (g*W + r) that need the selection
+    uint32_t *sc_node;     // [n_need][N]
+    double *sc_tot;        // [n_need][N]
+    int *sc_n;             // [n_need]
+    uint32_t *cand_node;
+    double *cand_tot;
+    int *cand_n;
+    double ratio_lin;
+    int K;  // entries kept: 400 (ArrayVec capacity) or n_active_nodes (top_nodes, table.rs:127-131)
+};
+void launch_select_top(const Top400Args &ta, unsigned n, hipStream_t s);
+
 void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_lanes, MappingSink *sink,
                             const Plan &plan, int g0, uint64_t R);
 

@@ -235,21 +235,6 @@ __device__ __forceinline__ int block_count(int local, int *lds_i) {
     return *lds_i;
 }
 
-struct Top400Args {
-    DenseArgs d;
-    int W;
-    const int *sw;
-    const uint32_t *need;  // lanes (g*W + r) that need the selection
-    uint32_t *sc_node;     // [n_need][N]
-    double *sc_tot;        // [n_need][N]
-    int *sc_n;             // [n_need]
-    uint32_t *cand_node;
-    double *cand_tot;
-    int *cand_n;
-    double ratio_lin;
-    int K;  // entries kept: 400 (ArrayVec capacity) or n_active_nodes (top_nodes, table.rs:127-131)
-};
-
 __global__ void __launch_bounds__(BLOCK) select_top400(const Top400Args a) {
     __shared__ int cnt;
     const uint32_t gi = a.need[blockIdx.x];
@@ -329,6 +314,11 @@ __global__ void __launch_bounds__(BLOCK) select_top400(const Top400Args a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) a.cand_n[gi] = cnt < K ? cnt : K;
+}
+
+void launch_select_top(const Top400Args &ta, unsigned n, hipStream_t s) {
+    hipLaunchKernelGGL(select_top400, dim3(n), dim3(BLOCK), 0, s, ta);
+    HIP_CHECK(hipGetLastError());
 }
 
 namespace {

@@ -194,6 +194,25 @@ class PHMMModel:
         f, b = self._tables(read, True, True)
         return PHMMOutput(self, bytes(read), f, b)
 
+    def backward_sparse(self, read: bytes):
+        """PHMMModel::backward_sparse (backward.rs:146-185) of one read -> (DenseTables with -inf where the
+        reference's sparse table holds no element, is_dense[L])."""
+        r = np.frombuffer(bytes(read), dtype=np.uint8)
+        L, N = r.shape[0], self.n_nodes
+        if L == 0:
+            raise _ffi.PhmmError(_ffi.PHMM_EINVAL, "empty read")
+        b = [np.empty((L, N)) for _ in range(3)] + [np.empty((L, 3))]
+        dense = np.zeros(L, dtype=np.uint8)
+        _ffi.check(_ffi.lib().phmm_backward_sparse_tables(self._h, _ptr(r), L, *[_ptr(x) for x in b], _ptr(dense)))
+        return DenseTables(*b), dense.astype(bool)
+
+    def to_full_prob_sparse_backward(self, reads: ReadCollection):
+        """PHMMModel::to_full_prob_sparse_backward (freq.rs:153-163) -> (total ln P, per-read ln P)."""
+        lp = np.empty(len(reads))
+        tot = np.empty(1)
+        _ffi.check(_ffi.lib().phmm_full_prob_sparse_backward(self._h, reads._h, _ptr(lp), _ptr(tot)))
+        return float(tot[0]), lp
+
     # ---- read-set drivers
     def run_dense(self, reads: ReadCollection, want_backward: bool = True, want_freq: bool = True,
                   out_logp=None, out_logp_backward=None, out_node_freq=None):

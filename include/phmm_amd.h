@@ -187,6 +187,21 @@ int phmm_full_prob_reads_copy_nums(phmm_model *m, const phmm_reads *reads,
                                    const uint32_t *copy_nums, uint32_t min_copy_num,
                                    double *out_logp, double *out_total);
 
+/* PHMMModel::to_full_prob_sparse_backward (freq.rs:153-163): ln P(read) from PHMMModel::backward_sparse
+ * (backward.rs:146-185) -- dense b_step over the last n_warmup positions, then the backward recursion on
+ * its own frontier: top_nodes(n_active_nodes) of the previous column, adaptive b_step (backward.rs:216-261).
+ *   out_logp[R] = B.tables[0].mb per read;  out_total = their sum.  Either may be NULL or a device pointer.
+ * n_warmup = 0 is PHMM_EINVAL (the reference panics in last_table(), table.rs:388). */
+int phmm_full_prob_sparse_backward(phmm_model *m, const phmm_reads *reads, double *out_logp,
+                                   double *out_total);
+
+/* The backward_sparse tables of ONE read for parity tests / `inspect`-style tools (bin/table.rs:41):
+ * b_m/b_i/b_d: [L][N] natural-log values of B.tables[i], -inf where the reference's SparseVec holds no
+ * element; b_scal: [L][3] = mb, ib, e; is_dense: [L] 1 for the dense tail.  Any pointer may be NULL.
+ * Host pointers. */
+int phmm_backward_sparse_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *b_m,
+                                double *b_i, double *b_d, double *b_scal, uint8_t *is_dense);
+
 /* Mapping carry-over between graphs: Mapping::map_nodes (hint.rs:60-88) for every read, the carrier of
  * MultiDbg::hint_kp1_from_hint_k (multi_dbg.rs:1325-1335: node of the k-HMM -> the k+1-HMM nodes of its
  * parent edges) and PurgeEdgeMap::update_mapping (multi_dbg.rs:1783-1793: node -> its id after purging, or

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import dbgphmm_amd as D
-from helpers import small_dbg_model
+from helpers import finite_close, small_dbg_model
 
 pytestmark = pytest.mark.gpu
 TOL_LOGP = 1e-9  # BASELINE.json bar: |delta ln P(R|X)| < 1e-6 per read
@@ -529,3 +529,53 @@ def test_unusual_frontier_parameters_match_oracle(gpu_lib, oracle, over):
     first = glp[gpo[:-1].astype(np.int64)]
     last = glp[gpo[1:].astype(np.int64) - 1]
     assert np.all(first - last < ratio + 1e-9)
+
+
+@pytest.mark.parametrize("cfg", [(600, 12, 0.01, 3, 40), (900, 16, 0.003, 21, 12), (300, 12, 0.001, 9, 5)])
+def test_backward_sparse_scores_match_oracle(gpu_lib, oracle, cfg):
+    """to_full_prob_sparse_backward (freq.rs:153-163) = backward_sparse(read).full_prob() (backward.rs:146-185):
+    dense over the last n_warmup positions, then top_nodes(n_active_nodes) + adaptive b_step."""
+    gl, k, p, seed, n_active = cfg
+    arrays, sg = small_dbg_model(gl, k, p, seed=seed)
+    arrays.param = arrays.param.with_(n_active_nodes=n_active)
+    reads = D.sample_reads(arrays, 10 ** 9, 150, seed=seed + 1, max_reads=30)
+    reads = [r[: max(3, len(r) - (j * 11) % 145)] for j, r in enumerate(reads)]  # some are all warm-up
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    tot, lp = gm.to_full_prob_sparse_backward(D.ReadCollection(reads))
+    olp = np.array([om.backward(r, oracle.BWD_SPARSE).full_prob() for r in reads])
+    assert np.max(np.abs(lp - olp)) < 1e-6, np.abs(lp - olp).max()
+    assert abs(tot - olp.sum()) < 1e-6 * len(reads)
+    # forward and backward totals of the sparse modes agree to 0.01 on the read set (hmmv2/tests/dbg.rs:44-45)
+    ftot, _ = gm.to_full_prob_reads(D.ReadCollection(reads), None, False)
+    assert abs(ftot - tot) < 0.01 * len(reads)
+
+
+@pytest.mark.parametrize("cfg", [(400, 12, 0.01, 3, 40, 100), (300, 12, 0.003, 9, 6, 70), (300, 12, 0.01, 5, 40, 9)])
+def test_backward_sparse_tables_match_oracle(gpu_lib, oracle, cfg):
+    """Every column of backward_sparse: the same elements (m, i on to_parents_and_us(top); d on the grown sets)
+    with the same values, the dense tail, and the Begin-state scalars."""
+    gl, k, p, seed, n_active, rl = cfg
+    arrays, sg = small_dbg_model(gl, k, p, seed=seed)
+    arrays.param = arrays.param.with_(n_active_nodes=n_active)
+    read = D.sample_reads(arrays, 10 ** 9, rl, seed=seed + 2, max_reads=1)[0]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    gt, dense = gm.backward_sparse(read)
+    ot = om.backward(read, oracle.BWD_SPARSE)
+    L = len(read)
+    assert dense.tolist() == [ot.is_dense(i) for i in range(L)]
+    for i in range(L):
+        m, ins, d, s = ot.table(i)
+        for name, g, o in (("m", gt.m[i], m), ("i", gt.i[i], ins), ("d", gt.d[i], d)):
+            floor = np.max(o) - 600.0 if dense[i] else None  # the dense kernel's scaled linear range
+            assert np.all(finite_close(g, o, 1e-8, floor)), (i, name, dense[i])
+        assert abs(gt.scal[i, 0] - s[0]) < 1e-8 and abs(gt.scal[i, 1] - s[1]) < 1e-8, (i, gt.scal[i], s)
+        assert np.isneginf(gt.scal[i, 2]) and np.isneginf(s[2])
+    assert abs(gt.scal[0, 0] - ot.full_prob()) < 1e-8
+
+
+def test_backward_sparse_rejects_zero_warmup(gpu_lib):
+    """n_warmup = 0: the reference's backward_sparse panics in last_table() (table.rs:388)."""
+    arrays, _ = small_dbg_model(300, 12, 0.01, seed=5)
+    arrays.param = arrays.param.with_(n_warmup=0)
+    with pytest.raises(D.PhmmError):  # (rejected with the parameters already: check_params)
+        D.PHMMModel(arrays).to_full_prob_sparse_backward(D.ReadCollection([b"ACGTACGTAC"]))
