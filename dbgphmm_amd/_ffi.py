@@ -73,6 +73,7 @@ def lib():
         "phmm_run_dense_edges": (i32, [vp, vp, vp, vp, vp]),
         "phmm_full_prob_sparse_backward": (i32, [vp, vp, vp, vp]),
         "phmm_backward_sparse_tables": (i32, [vp, vp, u64, vp, vp, vp, vp, vp]),
+        "phmm_run_sparse": (i32, [vp, vp, vp, vp, vp]),
         "phmm_q_score_exact": (i32, [vp, vp, vp, vp]),
         "phmm_mappings_map_nodes": (i32, [vp, vp, vp, vp, vp, u32, vp]),
         "phmm_full_prob_reads_candidates": (i32, [vp, vp, vp, u32, vp, vp, vp, vp]),
@@ -94,7 +95,7 @@ DECLARED_SYMBOLS = [
     "phmm_set_workspace_limit", "phmm_params_new", "phmm_params_uniform", "phmm_model_create",
     "phmm_model_set_probs", "phmm_model_set_params", "phmm_model_n_nodes", "phmm_model_n_edges",
     "phmm_model_destroy", "phmm_reads_create", "phmm_reads_count", "phmm_reads_total_bases",
-    "phmm_reads_destroy", "phmm_run_dense", "phmm_run_dense_edges", "phmm_q_score_exact", "phmm_full_prob_sparse_backward", "phmm_backward_sparse_tables", "phmm_dense_tables", "phmm_mappings_create",
+    "phmm_reads_destroy", "phmm_run_dense", "phmm_run_dense_edges", "phmm_q_score_exact", "phmm_run_sparse", "phmm_full_prob_sparse_backward", "phmm_backward_sparse_tables", "phmm_dense_tables", "phmm_mappings_create",
     "phmm_mappings_total_positions", "phmm_mappings_total_entries", "phmm_mappings_export",
     "phmm_mappings_node_freqs", "phmm_mappings_read_logp", "phmm_mappings_map_nodes", "phmm_mappings_destroy", "phmm_full_prob_reads",
     "phmm_full_prob_reads_candidates", "phmm_full_prob_reads_copy_nums", "phmm_generate_mappings", "phmm_last_call_stats", "phmm_enable_timing",

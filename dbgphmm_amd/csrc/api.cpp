@@ -348,6 +348,24 @@ int phmm_full_prob_sparse_backward(phmm_model *m, const phmm_reads *reads, doubl
     });
 }
 
+int phmm_run_sparse(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb, double *out_nf) {
+    return guarded([&] {
+        if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
+        if (reads->R == 0) {
+            if (out_nf) {
+                std::vector<double> z(m->N, 0.0);
+                DevBuf b;
+                b.upload(z.data(), z.size() * sizeof(double));
+                copy_out(out_nf, b.p, z.size() * sizeof(double));
+            }
+            return;
+        }
+        for (uint64_t r = 0; r < reads->R; r++)
+            if (reads->off[r + 1] == reads->off[r]) PHMM_THROW(PHMM_EINVAL, "empty read (reference panics: table.rs:388)");
+        run_sparse(m, reads, out_lf, out_lb, out_nf);
+    });
+}
+
 int phmm_backward_sparse_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *b_m, double *b_i, double *b_d,
                                 double *b_scal, uint8_t *is_dense) {
     return guarded([&] {

@@ -294,6 +294,7 @@ void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *o
 void full_prob_sparse_backward(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total);
 void backward_sparse_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *b_m, double *b_i, double *b_d,
                             double *b_scal, uint8_t *is_dense);
+void run_sparse(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb, double *out_nf);
 void run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_ef, double *out_if);
 struct RecPool;
 // sparse / hinted drivers (sparse.hip)

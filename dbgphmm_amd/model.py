@@ -206,6 +206,13 @@ class PHMMModel:
         _ffi.check(_ffi.lib().phmm_backward_sparse_tables(self._h, _ptr(r), L, *[_ptr(x) for x in b], _ptr(dense)))
         return DenseTables(*b), dense.astype(bool)
 
+    def run_sparse(self, reads: ReadCollection):
+        """PHMMModel::run_sparse (freq.rs:51-55) over a read set -> (ln P forward[R], ln P backward[R],
+        node_freq[N] summed over the reads)."""
+        lf, lb, nf = np.empty(len(reads)), np.empty(len(reads)), np.empty(self.n_nodes)
+        _ffi.check(_ffi.lib().phmm_run_sparse(self._h, reads._h, _ptr(lf), _ptr(lb), _ptr(nf)))
+        return lf, lb, nf
+
     def to_full_prob_sparse_backward(self, reads: ReadCollection):
         """PHMMModel::to_full_prob_sparse_backward (freq.rs:153-163) -> (total ln P, per-read ln P)."""
         lp = np.empty(len(reads))

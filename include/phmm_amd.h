@@ -195,6 +195,15 @@ int phmm_full_prob_reads_copy_nums(phmm_model *m, const phmm_reads *reads,
 int phmm_full_prob_sparse_backward(phmm_model *m, const phmm_reads *reads, double *out_logp,
                                    double *out_total);
 
+/* PHMMModel::run_sparse over a read set (freq.rs:51-55): forward_sparse(use_max_ratio = false) paired with
+ * backward_sparse, followed by PHMMOutput::{to_full_prob_forward, to_full_prob_backward, to_node_freqs}
+ * (table.rs:482-494; freq.rs:245-255): the product of a dense and a sparse table keeps the sparse operand's
+ * elements, of two sparse tables the forward one's (table.rs:320-331).
+ *   out_logp_forward[R], out_logp_backward[R], out_node_freq[N] (summed over the reads); any may be NULL or a
+ * device pointer.  Keeps the dense head / tail columns and every sparse column of a chunk in HBM. */
+int phmm_run_sparse(phmm_model *m, const phmm_reads *reads, double *out_logp_forward,
+                    double *out_logp_backward, double *out_node_freq);
+
 /* The backward_sparse tables of ONE read for parity tests / `inspect`-style tools (bin/table.rs:41):
  * b_m/b_i/b_d: [L][N] natural-log values of B.tables[i], -inf where the reference's SparseVec holds no
  * element; b_scal: [L][3] = mb, ib, e; is_dense: [L] 1 for the dense tail.  Any pointer may be NULL.

@@ -579,3 +579,35 @@ def test_backward_sparse_rejects_zero_warmup(gpu_lib):
     arrays.param = arrays.param.with_(n_warmup=0)
     with pytest.raises(D.PhmmError):  # (rejected with the parameters already: check_params)
         D.PHMMModel(arrays).to_full_prob_sparse_backward(D.ReadCollection([b"ACGTACGTAC"]))
+
+
+@pytest.mark.parametrize("cfg", [(600, 12, 0.01, 3, 40, 150), (300, 12, 0.003, 9, 6, 70), (400, 16, 0.01, 5, 20, 40)])
+def test_run_sparse_node_freqs_match_oracle(gpu_lib, oracle, cfg):
+    """run_sparse (freq.rs:51-55) + to_node_freqs (freq.rs:245-255) summed over the reads: dense x sparse,
+    sparse x dense, sparse x sparse and (short reads) dense x dense merged indices."""
+    gl, k, p, seed, n_active, rl = cfg
+    arrays, sg = small_dbg_model(gl, k, p, seed=seed, min_copy_num=1)
+    arrays.param = arrays.param.with_(n_active_nodes=n_active)
+    reads = D.sample_reads(arrays, 10 ** 9, rl, seed=seed + 1, max_reads=24)
+    reads = [r[: max(2, len(r) - (j * 11) % (rl - 5))] for j, r in enumerate(reads)]  # all-warm-up and overlap cases
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    lf, lb, nf = gm.run_sparse(D.ReadCollection(reads))
+    onf = np.zeros(arrays.n_nodes)
+    nw = arrays.param.n_warmup
+    for j, r in enumerate(reads):
+        o = om.run_sparse(r)
+        assert abs(lf[j] - o.to_full_prob_forward()) < 1e-6, j
+        assert abs(lb[j] - o.to_full_prob_backward()) < 1e-6, j
+        # state_probs = sum over merged indices of the emit probs (freq.rs:236-243), summed here without the
+        # 400-element capacity of a sparse accumulator
+        one = np.zeros(arrays.n_nodes)
+        for jj in range(len(r) + 1):
+            m, i, d, _ = o.to_emit_probs(jj)
+            one += np.exp(m) + np.exp(i) + np.exp(d)
+        if not (nw < len(r) < 2 * nw and arrays.n_nodes > 400):
+            assert np.max(np.abs(one - o.to_node_freqs())) < 1e-9, j
+        # (nw < len < 2 nw: dense emit-prob tables are added INTO a sparse accumulator; with N > 400 the
+        # oracle's accumulator drops elements and the reference's SparseVec behaviour there is unpinned)
+        onf += one
+    assert np.max(np.abs(nf - onf)) < 1e-9 * len(reads), np.abs(nf - onf).max()
+    assert abs(nf.sum() - sum(map(len, reads))) < 0.02 * sum(map(len, reads))

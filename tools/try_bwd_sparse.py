@@ -20,3 +20,6 @@ for it in range(2):
 for it in range(2):
     t = time.time(); btot, blp = gm.to_full_prob_sparse_backward(rc); dt = time.time() - t
     print(f"backward_sparse      {dt:.3f}s {nb/dt:.3e} bases/s tot={btot:.3f} max|f-b|={np.abs(flp-blp).max():.3e}", flush=True)
+for it in range(2):
+    t = time.time(); lf, lb, nf = gm.run_sparse(rc); dt = time.time() - t
+    print(f"run_sparse           {dt:.3f}s {nb/dt:.3e} bases/s nfsum={nf.sum():.1f} max|lf-flp|={np.abs(lf-flp).max():.2e} max|lb-blp|={np.abs(lb-blp).max():.2e}", flush=True)
