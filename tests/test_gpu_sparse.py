@@ -550,7 +550,8 @@ def test_backward_sparse_scores_match_oracle(gpu_lib, oracle, cfg):
     assert abs(ftot - tot) < 0.01 * len(reads)
 
 
-@pytest.mark.parametrize("cfg", [(400, 12, 0.01, 3, 40, 100), (300, 12, 0.003, 9, 6, 70), (300, 12, 0.01, 5, 40, 9)])
+@pytest.mark.parametrize("cfg", [(400, 12, 0.01, 3, 40, 100), (300, 12, 0.003, 9, 6, 70), (300, 12, 0.01, 5, 40, 9),
+                                 (600, 12, 0.01, 7, 300, 60)])  # the last: the grown sets reach the 400-slot capacity
 def test_backward_sparse_tables_match_oracle(gpu_lib, oracle, cfg):
     """Every column of backward_sparse: the same elements (m, i on to_parents_and_us(top); d on the grown sets)
     with the same values, the dense tail, and the Begin-state scalars."""
