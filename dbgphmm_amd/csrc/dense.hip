@@ -1164,7 +1164,7 @@ static void launch_edge_freq(int W, const DenseArgs &a, const uint32_t *esrc, co
 void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, uint64_t R,
                     const Plan &plan, bool full_b, bool eall, bool want_b, bool want_freq,
                     double *out_lf, double *out_lb, double *out_nf, DenseArgs *dbg_args, double *out_ef,
-                    double *out_if) {
+                    double *out_if, std::vector<uint32_t> *flagged_out) {
     hipStream_t s = current_stream();
     CallStats &st = stats();
     st = CallStats();
@@ -1245,6 +1245,78 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
         st.cells[0] += cells;
         if (want_b || want_freq) st.cells[1] += cells;
 
+        // ---- certificate of the scaled linear domain (exact_dense.hip): reads whose flushed cells could matter
+        std::vector<uint32_t> flagged;  // lanes of this chunk
+        {
+            const size_t nE = (size_t)ngc * (Lc + 1) * W, nC = (size_t)ngc * Lc * W;
+            std::vector<int> hFE(nE), hBE;
+            std::vector<unsigned long long> hcF(nC), hcB;
+            std::vector<double> hP((size_t)ngc * W);
+            HIP_CHECK(hipMemcpyAsync(hFE.data(), a.FE, sizeof(int) * nE, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(hcF.data(), a.cmaxF, sizeof(unsigned long long) * nC, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(hP.data(), a.logPf, sizeof(double) * hP.size(), hipMemcpyDeviceToHost, s));
+            bool have_b = want_b || want_freq;
+            auto fetch_b = [&] {
+                hBE.resize(nE);
+                hcB.resize(nC);
+                HIP_CHECK(hipMemcpyAsync(hBE.data(), a.BE, sizeof(int) * nE, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipMemcpyAsync(hcB.data(), a.cmaxB, sizeof(unsigned long long) * nC, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+            };
+            if (have_b) fetch_b();
+            else HIP_CHECK(hipStreamSynchronize(s));
+            const double l2pe = std::log2(m->lin.p_end);
+            std::vector<int> fe(Lc), be(Lc);
+            std::vector<double> mf(Lc), mbx(Lc);
+            auto l2 = [](unsigned long long bits) {
+                double v;
+                std::memcpy(&v, &bits, 8);
+                return v > 0.0 ? std::log2(v) : -INFINITY;
+            };
+            auto check = [&](int gi, bool with_b) {
+                const int g = gi / W, r = gi % W, len = hl[gi];
+                for (int i = 0; i < len; i++) {
+                    fe[i] = hFE[((size_t)g * (Lc + 1) + i) * W + r];
+                    mf[i] = l2(hcF[((size_t)g * Lc + i) * W + r]) + fe[i];
+                    if (with_b) {
+                        be[i] = hBE[((size_t)g * (Lc + 1) + i) * W + r];
+                        mbx[i] = l2(hcB[((size_t)g * Lc + i) * W + r]) + be[i];
+                    }
+                }
+                return certify_dense((int)m->N, len, hP[gi] / LN2, fe.data(), mf.data(), with_b ? be.data() : nullptr,
+                                     with_b ? mbx.data() : nullptr, l2pe);
+            };
+            std::vector<uint32_t> doubt;
+            for (int gi = 0; gi < ngc * W; gi++)
+                if (hl[gi] > 0 && !check(gi, have_b)) doubt.push_back((uint32_t)gi);
+            if (!doubt.empty() && !have_b) {
+                // forward-only call: the bound with B <= 1 is loose; get the backward maxima and look again
+                for (int pos = Lc - 1; pos >= 0; pos--) launch_bwd_step(W, a, pos);
+                launch_bwd_finish(W, a);
+                fetch_b();
+                for (uint32_t gi : doubt)
+                    if (!check((int)gi, true)) flagged.push_back(gi);
+            } else {
+                flagged.swap(doubt);
+            }
+        }
+        if (!flagged.empty()) {
+            if (want_edge)
+                PHMM_THROW(PHMM_ERANGE, "transition posteriors: a read leaves the dynamic range of the dense kernels (no exact path)");
+            if (want_freq) {
+                // their (unreliable) posteriors are in accg: redo the chunk without them
+                HIP_CHECK(hipMemsetAsync(m->wset().misc.p, 0, mb, s));
+                std::vector<int> hl2 = hl;
+                for (uint32_t gi : flagged) hl2[gi] = 0;
+                HIP_CHECK(hipMemcpyAsync((void *)a.bases, hb.data(), hb.size(), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipMemcpyAsync((void *)a.len, hl2.data(), hl2.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipMemcpyAsync((void *)a.logib, hib.data(), hib.size() * sizeof(double), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                launch_chunk_w(W, a, true, st, false);
+            }
+            trace("dense: reads outside the scaled range");
+        }
+
         if (want_freq)
             hipLaunchKernelGGL(freq_reduce, dim3((m->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, a.accg, ngc,
                                (int)m->N, nf_dev.as<double>(), first_chunk ? 0 : 1);
@@ -1278,6 +1350,30 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
                 lf[rd] = tlf[(size_t)g * W + r];
                 if (want_b) lb[rd] = tmb[((size_t)g * (Lc + 1) + 0) * W + r];
             }
+        if (!flagged.empty()) {
+            // exact log-domain recursion for the flagged reads, a few at a time (their full tables stay in HBM)
+            std::vector<uint32_t> ids;
+            for (uint32_t gi : flagged) ids.push_back(plan.order[(size_t)g0 * W + gi]);
+            if (flagged_out) flagged_out->insert(flagged_out->end(), ids.begin(), ids.end());
+            size_t j0 = 0;
+            while (j0 < ids.size()) {
+                size_t j1 = j0, bytes = 0;
+                while (j1 < ids.size()) {
+                    const size_t need = (size_t)(off[ids[j1] + 1] - off[ids[j1]]) * m->N * 24;
+                    if (j1 > j0 && bytes + need > ((size_t)8 << 30)) break;
+                    bytes += need;
+                    j1++;
+                }
+                std::vector<uint32_t> part(ids.begin() + j0, ids.begin() + j1);
+                std::vector<double> xlf(part.size()), xlb(part.size());
+                exact_dense_reads(m, bases, off, part, xlf.data(), xlb.data(), want_freq ? nf_dev.as<double>() : nullptr, nullptr);
+                for (size_t j = 0; j < part.size(); j++) {
+                    lf[part[j]] = xlf[j];
+                    if (want_b) lb[part[j]] = xlb[j];
+                }
+                j0 = j1;
+            }
+        }
         if (dbg_args) *dbg_args = a;
         g0 += ngc;
         first_chunk = false;
@@ -1305,13 +1401,13 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
 void run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_ef, double *out_if) {
     Plan plan = make_plan(m, reads, 0);
     run_dense_impl(m, reads->bases.data(), reads->off.data(), reads->R, plan, true, false, true, false, out_lf, nullptr,
-                   nullptr, nullptr, out_ef, out_if);
+                   nullptr, nullptr, out_ef, out_if, nullptr);
 }
 
 void run_dense(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb, double *out_nf) {
     Plan plan = make_plan(m, reads, 0);
     run_dense_impl(m, reads->bases.data(), reads->off.data(), reads->R, plan, false, false, out_lb != nullptr,
-                   out_nf != nullptr, out_lf, out_lb, out_nf, nullptr, nullptr, nullptr);
+                   out_nf != nullptr, out_lf, out_lb, out_nf, nullptr, nullptr, nullptr, nullptr);
 }
 
 void dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i, double *f_d,
@@ -1327,8 +1423,15 @@ void dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m,
     const bool want_b = b_m || b_i || b_d || b_scal;
     DenseArgs a{};
     double lf = 0, lb = 0;
+    std::vector<uint32_t> flagged;
     run_dense_impl(m, one.bases.data(), one.off.data(), 1, plan, true, true, want_b, false, &lf, want_b ? &lb : nullptr,
-                   nullptr, &a, nullptr, nullptr);
+                   nullptr, &a, nullptr, nullptr, &flagged);
+    if (!flagged.empty()) {
+        // outside the scaled range: the tables of the exact recursion instead (exact_dense.hip)
+        ExactTables et{f_m, f_i, f_d, f_scal, b_m, b_i, b_d, b_scal};
+        exact_dense_reads(m, one.bases.data(), one.off.data(), flagged, nullptr, nullptr, nullptr, &et);
+        return;
+    }
     const int L = (int)len, N = (int)m->N;
     const size_t n = (size_t)L * N;
     DevBuf tmp;

@@ -87,4 +87,13 @@ void launch_fwd_finish(int W, const DenseArgs &a);
 void launch_bwd_step(int W, const DenseArgs &a, int pos);
 void launch_bwd_finish(int W, const DenseArgs &a);
 
+// exact_dense.hip: the log-domain dense recursion for reads the scaled linear kernels cannot certify
+struct ExactTables {
+    double *f_m, *f_i, *f_d, *f_scal, *b_m, *b_i, *b_d, *b_scal;  // [L][N] / [L][3] host arrays, any may be null
+};
+void exact_dense_reads(phmm_model *m, const uint8_t *bases, const uint64_t *off, const std::vector<uint32_t> &ids, double *lf,
+                       double *lb, double *freq_dev, const ExactTables *tabs);
+bool certify_dense(int N, int len, double log2P, const int *FE, const double *log2maxF, const int *BE, const double *log2maxB,
+                   double log2_p_end);
+
 }  // namespace phmm

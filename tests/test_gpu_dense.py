@@ -178,6 +178,36 @@ def test_edge_and_init_freqs_match_oracle(gpu_lib, oracle, n_reads):
     assert abs(nf.sum() - len(reads)) < 0.01 * len(reads)
 
 
+def test_chimeric_read_takes_the_exact_path(gpu_lib, oracle):
+    """A read whose halves come from different places: cells thousands of nats below the column maximum grow back
+    after the junction.  The scaled linear kernels flush them; the driver's certificate (exact_dense.hip:
+    certify_dense) sends the read through the log-domain recursion, the others stay on the fast path."""
+    arrays, sg = small_dbg_model(500, 12, 0.01, seed=17, min_copy_num=1)
+    chim = b"".join(D.sample_reads(arrays, 10 ** 9, 400, seed=9, max_reads=6))  # six reads' worth of bases from 6 places
+    normal = D.sample_reads(arrays, 10 ** 9, 120, seed=3, max_reads=4)
+    reads = [normal[0], chim, normal[1], normal[2]]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    lf, lb, nf = gm.run_dense(rc)
+    olf, olb, onf = om.run_dense_reads(reads, n_threads=8)
+    assert np.max(np.abs(lf - olf)) < 1e-6 and np.max(np.abs(lb - olb)) < 1e-6
+    assert np.max(np.abs(nf - onf)) < 1e-6
+    lf2, _, _ = gm.run_dense(rc, False, False)  # forward only: the certificate fetches the backward maxima itself
+    assert np.max(np.abs(lf2 - olf)) < 1e-6
+    # tables of the chimeric read alone (phmm_dense_tables)
+    out = gm.run(chim)
+    oo = om.run(chim)
+    L = len(chim)
+    for i in (0, L // 6 - 1, L // 6, L // 6 + 1, L // 2, L - 1):
+        m, ins, d, sc = oo.forward.table(i)
+        assert np.all(finite_close(out.forward.m[i], m, 1e-6)) and np.all(finite_close(out.forward.d[i], d, 1e-6))
+        assert abs(out.forward.scal[i, 2] - sc[2]) < 1e-6
+        m, ins, d, sc = oo.backward.table(i)
+        assert np.all(finite_close(out.backward.m[i], m, 1e-6)) and np.all(finite_close(out.backward.i[i], ins, 1e-6))
+        assert abs(out.backward.scal[i, 0] - sc[0]) < 1e-6
+    assert np.max(np.abs(out.to_node_freqs() - oo.to_node_freqs())) < 1e-6
+
+
 def test_q_score_exact(gpu_lib, oracle):
     """q_score_exact (q.rs:66-96): init = sum init_freq * ln init, trans = sum edge_freq * ln trans over emittable
     nodes / edges between emittable nodes, prior = 0.  The reference holds no KAT for it: the expected value is the
