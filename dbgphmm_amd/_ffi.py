@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphmm_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-PHMM_OK, PHMM_EINVAL, PHMM_ENODEVICE, PHMM_ENOMEM, PHMM_ECAPACITY, PHMM_EINTERNAL, PHMM_ERANGE = 0, -1, -2, -3, -4, -5, -6
+PHMM_OK, PHMM_EINVAL, PHMM_ENODEVICE, PHMM_ENOMEM, PHMM_ECAPACITY, PHMM_EINTERNAL = 0, -1, -2, -3, -4, -5
 
 
 class PhmmError(RuntimeError):

@@ -1301,9 +1301,7 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
             }
         }
         if (!flagged.empty()) {
-            if (want_edge)
-                PHMM_THROW(PHMM_ERANGE, "transition posteriors: a read leaves the dynamic range of the dense kernels (no exact path)");
-            if (want_freq) {
+            if (want_freq || want_edge) {
                 // their (unreliable) posteriors are in accg: redo the chunk without them
                 HIP_CHECK(hipMemsetAsync(m->wset().misc.p, 0, mb, s));
                 std::vector<int> hl2 = hl;
@@ -1359,14 +1357,15 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
             while (j0 < ids.size()) {
                 size_t j1 = j0, bytes = 0;
                 while (j1 < ids.size()) {
-                    const size_t need = (size_t)(off[ids[j1] + 1] - off[ids[j1]]) * m->N * 24;
+                    const size_t need = (size_t)(off[ids[j1] + 1] - off[ids[j1]]) * m->N * (want_edge ? 48 : 24);
                     if (j1 > j0 && bytes + need > ((size_t)8 << 30)) break;
                     bytes += need;
                     j1++;
                 }
                 std::vector<uint32_t> part(ids.begin() + j0, ids.begin() + j1);
                 std::vector<double> xlf(part.size()), xlb(part.size());
-                exact_dense_reads(m, bases, off, part, xlf.data(), xlb.data(), want_freq ? nf_dev.as<double>() : nullptr, nullptr);
+                exact_dense_reads(m, bases, off, part, xlf.data(), xlb.data(), want_freq ? nf_dev.as<double>() : nullptr, nullptr,
+                                  want_edge && m->E ? ef_dev.as<double>() : nullptr, want_edge ? if_dev.as<double>() : nullptr);
                 for (size_t j = 0; j < part.size(); j++) {
                     lf[part[j]] = xlf[j];
                     if (want_b) lb[part[j]] = xlb[j];

@@ -92,7 +92,8 @@ struct ExactTables {
     double *f_m, *f_i, *f_d, *f_scal, *b_m, *b_i, *b_d, *b_scal;  // [L][N] / [L][3] host arrays, any may be null
 };
 void exact_dense_reads(phmm_model *m, const uint8_t *bases, const uint64_t *off, const std::vector<uint32_t> &ids, double *lf,
-                       double *lb, double *freq_dev, const ExactTables *tabs);
+                       double *lb, double *freq_dev, const ExactTables *tabs, double *edge_freq_dev = nullptr,
+                       double *init_freq_dev = nullptr);
 bool certify_dense(int N, int len, double log2P, const int *FE, const double *log2maxF, const int *BE, const double *log2maxB,
                    double log2_p_end);
 

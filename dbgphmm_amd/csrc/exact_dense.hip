@@ -214,12 +214,61 @@ __global__ void __launch_bounds__(XB) exact_dense_kernel(const ExactArgs a) {
     }
 }
 
+// Transition posteriors of the same reads from their kept tables (freq.rs:276-298, 332-389): item < E is the PHMM
+// edge k -> l (kinds mm im dm md id dd over the merged indices 1..len), item >= E the Begin -> l transitions
+// (mm im md id over 0..len).  One thread per (item, read).
+__global__ void __launch_bounds__(256) exact_edge_kernel(const ExactArgs a, const uint32_t *esrc, const uint32_t *edst, int E,
+                                                         double *ef, double *inf) {
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= E + a.N) return;
+    const int rid = blockIdx.y, N = a.N;
+    const bool is_edge = item < E;
+    const int k = is_edge ? (int)esrc[item] : 0;
+    const int l = is_edge ? (int)edst[item] : item - E;
+    const double t = is_edge ? a.trans_l[item] : a.init_l[l];
+    if (!(t > -INFINITY)) return;
+    const uint64_t o = a.roff[rid];
+    const int L = (int)(a.roff[rid + 1] - o);
+    const uint8_t *x = a.bases + o;
+    const phmm_params &p = a.p;
+    const double *Fm = a.Fm + o * N, *Fi = a.Fi + o * N, *Fd = a.Fd + o * N;
+    const double *Bm = a.Bm + o * N, *Bd = a.Bd + o * N;
+    const double *fs = a.fscal + o * 3;
+    const double P = fs[3 * (L - 1) + 2];
+    if (!(P > -INFINITY)) return;
+    const uint8_t el = a.emis[l];
+    double acc = 0.0;
+    for (int i = is_edge ? 1 : 0; i <= L; i++) {
+        double sm, sd;  // source side: F.table_merged(i), to Match / to Del
+        if (is_edge) {
+            const size_t q = (size_t)(i - 1) * N + k;
+            sm = lse3(p.p_MM + Fm[q], p.p_IM + Fi[q], p.p_DM + Fd[q]);
+            sd = lse3(p.p_MD + Fm[q], p.p_ID + Fi[q], p.p_DD + Fd[q]);
+        } else if (i == 0) {
+            sm = p.p_MM;
+            sd = p.p_MD;
+        } else {
+            const double ib = fs[3 * (i - 1) + 1];
+            sm = p.p_IM + ib;
+            sd = p.p_ID + ib;
+        }
+        if (i < L) {
+            const double pe = el == x[i] ? p.p_match : p.p_mismatch;
+            const double bm = i + 1 < L ? Bm[(size_t)(i + 1) * N + l] : p.p_end;
+            acc += exp(t + sm + pe + bm - P) + exp(t + sd + Bd[(size_t)i * N + l] - P);
+        } else {
+            acc += exp(t + sd + p.p_end - P);
+        }
+    }
+    if (acc != 0.0) atomicAdd(is_edge ? &ef[item] : &inf[l], acc);
+}
+
 }  // namespace
 
 // Reads `ids` of the read set, exactly.  lf / lb: per listed read; freq_dev: device [N], accumulated into;
 // tabs (one read): [L][N] tables and [L][3] scalars to the host.
 void exact_dense_reads(phmm_model *m, const uint8_t *bases, const uint64_t *off, const std::vector<uint32_t> &ids, double *lf,
-                       double *lb, double *freq_dev, const ExactTables *tabs) {
+                       double *lb, double *freq_dev, const ExactTables *tabs, double *edge_freq_dev, double *init_freq_dev) {
     hipStream_t s = current_stream();
     const size_t n = ids.size();
     if (n == 0) return;
@@ -229,7 +278,8 @@ void exact_dense_reads(phmm_model *m, const uint8_t *bases, const uint64_t *off,
     const uint64_t npos = roff[n];
     std::vector<uint8_t> hb(npos);
     for (size_t j = 0; j < n; j++) std::memcpy(hb.data() + roff[j], bases + off[ids[j]], roff[j + 1] - roff[j]);
-    const bool keep_b = tabs != nullptr;
+    const bool want_edges = edge_freq_dev || init_freq_dev;
+    const bool keep_b = tabs != nullptr || want_edges;
     DevBuf d_init, d_trans, d_bases, d_roff, tF, tB, lev, scal, outs;
     d_init.upload(m->init_logp.data(), sizeof(double) * N);
     d_trans.upload(m->trans_logp.data(), sizeof(double) * m->E);
@@ -270,6 +320,17 @@ void exact_dense_reads(phmm_model *m, const uint8_t *bases, const uint64_t *off,
     a.freq = freq_dev;
     hipLaunchKernelGGL(exact_dense_kernel, dim3((unsigned)n), dim3(XB), 0, s, a);
     HIP_CHECK(hipGetLastError());
+    DevBuf d_esrc, d_edst, dump;
+    if (want_edges) {
+        d_esrc.upload(m->esrc.data(), sizeof(uint32_t) * m->E);
+        d_edst.upload(m->edst.data(), sizeof(uint32_t) * m->E);
+        dump.reserve(sizeof(double) * std::max<size_t>(std::max<size_t>(m->E, N), 1));  // sink of an output not asked for
+        const unsigned items = (unsigned)(m->E + N);
+        hipLaunchKernelGGL(exact_edge_kernel, dim3((items + 255) / 256, (unsigned)n), dim3(256), 0, s, a, d_esrc.as<uint32_t>(),
+                           d_edst.as<uint32_t>(), (int)m->E, edge_freq_dev ? edge_freq_dev : dump.as<double>(),
+                           init_freq_dev ? init_freq_dev : dump.as<double>());
+        HIP_CHECK(hipGetLastError());
+    }
     std::vector<double> ho(2 * n);
     HIP_CHECK(hipMemcpyAsync(ho.data(), outs.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));

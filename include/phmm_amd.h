@@ -38,7 +38,6 @@ extern "C" {
 #define PHMM_ENOMEM (-3)    /* device or host allocation failed */
 #define PHMM_ECAPACITY (-4) /* >400 active nodes (reference: ArrayVec panic, table.rs:22) */
 #define PHMM_EINTERNAL (-5)
-#define PHMM_ERANGE (-6)    /* a read outside the dynamic range of the scaled dense kernels where no exact path exists */
 
 #define PHMM_MAX_ACTIVE_NODES 400 /* src/hmmv2/table.rs:22 */
 #define PHMM_MAX_GAPS 6           /* supported upper bound of n_max_gaps (reference default 4) */

@@ -194,6 +194,15 @@ def test_chimeric_read_takes_the_exact_path(gpu_lib, oracle):
     assert np.max(np.abs(nf - onf)) < 1e-6
     lf2, _, _ = gm.run_dense(rc, False, False)  # forward only: the certificate fetches the backward maxima itself
     assert np.max(np.abs(lf2 - olf)) < 1e-6
+    # transition posteriors (freq.rs:276-298) of the same batch
+    lf3, ef, inf = gm.run_dense_edge_freqs(rc)
+    oef, oinf = np.zeros(arrays.n_edges), np.zeros(arrays.n_nodes)
+    for r in reads:
+        e1, n1 = om.run(r).to_edge_and_init_freqs()
+        oef += e1
+        oinf += n1
+    assert np.max(np.abs(lf3 - olf)) < 1e-6
+    assert np.max(np.abs(ef - oef)) < 1e-6 and np.max(np.abs(inf - oinf)) < 1e-6
     # tables of the chimeric read alone (phmm_dense_tables)
     out = gm.run(chim)
     oo = om.run(chim)
