@@ -32,24 +32,49 @@ struct LeanLane {
     double pm, pi, pd;    // previous column (scaled), 0 for a node new to the frontier
     double m, i, d;       // current column
     int pl[ADJ_DEG];      // lanes of the parents (-1: not in the frontier)
+    bool miss;            // some child is not in the frontier
 };
 
 // Children of the nodes on the lanes of `src`: lanes that hold them are returned as a mask; children
 // that are not in the frontier yet take free lanes (their records are fetched).  Returns false when
 // the free lanes do not suffice (nothing is modified in that case except hash cells of the keys that
 // could not be placed -- the caller abandons the column).
-__device__ __forceinline__ bool ln_expand(const SparseModel &M, LeanShared &sh, LeanLane &L, unsigned long long src,
-                                           unsigned long long &out, int &inserted) {
+__device__ __forceinline__ void ln_links(const LeanShared &sh, LeanLane &L) {
+#pragma unroll
+    for (int q = 0; q < ADJ_DEG; q++) L.pl[q] = (L.id != LN_EMPTY && q < (int)L.r.npar) ? ln_find(sh, L.r.par[q]) : -1;
+    bool miss = false;
+#pragma unroll
+    for (int q = 0; q < ADJ_DEG; q++) miss |= L.id != LN_EMPTY && q < (int)L.r.nchi && ln_find(sh, L.r.chi[q]) < 0;
+    L.miss = miss;
+}
+
+// lanes that hold a child of a lane of `src` = resident nodes with a parent on a lane of `src`
+__device__ __forceinline__ unsigned long long ln_children_of(const LeanLane &L, unsigned long long src) {
+    bool hit = false;
+#pragma unroll
+    for (int q = 0; q < ADJ_DEG; q++) hit |= L.pl[q] >= 0 && ((src >> L.pl[q]) & 1ull);
+    return __ballot(hit);
+}
+
+// The insertion half of an expansion, kept out of line (inlined next to the fast path it doubles the
+// kernel's registers): children of the `insrc` lanes that are not in the frontier yet are queued and the
+// free lanes take them in order.  Returns the number of new nodes (-1: the free lanes do not suffice; only
+// hash cells of keys that could not be placed are modified then) and, per lane, the node it has to adopt.
+struct LnAdopt {
+    int total;
+    uint32_t key;  // LN_EMPTY: this lane adopts nothing
+};
+__device__ __noinline__ LnAdopt ln_insert_children(LeanShared &sh, bool insrc, bool occupied, uint32_t c0, uint32_t c1,
+                                                   uint32_t c2, uint32_t c3, uint32_t c4, int nchi) {
     const int lane = threadIdx.x;
-    const bool insrc = (src >> lane) & 1ull;
-    if (lane == 0) sh.mark = 0ull;
+    const uint32_t chi[ADJ_DEG] = {c0, c1, c2, c3, c4};
     uint16_t hc[ADJ_DEG];
     uint32_t wins = 0;
 #pragma unroll
     for (int q = 0; q < ADJ_DEG; q++) {
         hc[q] = 0;
-        if (insrc && q < (int)L.r.nchi) {
-            const uint32_t key = L.r.chi[q];
+        if (insrc && q < nchi) {
+            const uint32_t key = chi[q];
             uint32_t h = ln_hash(key);
             for (;;) {
                 const uint32_t old = atomicCAS(&sh.hkey[h], LN_EMPTY, key);
@@ -67,15 +92,18 @@ __device__ __forceinline__ bool ln_expand(const SparseModel &M, LeanShared &sh, 
     const int nw = __popc(wins);
     const int incl = wave_iscan(nw);
     const int total = __shfl(incl, 63);
-    const unsigned long long freemask = ~__ballot(L.id != LN_EMPTY);
-    inserted = total;
-    if (total > __popcll(freemask)) return false;
+    const unsigned long long freemask = ~__ballot(occupied);
+    LnAdopt r{total, LN_EMPTY};
+    if (total > __popcll(freemask)) {
+        r.total = -1;
+        return r;
+    }
     if (total > 0) {
         int w = incl - nw;
 #pragma unroll
         for (int q = 0; q < ADJ_DEG; q++)
             if (wins & (1u << q)) {
-                sh.winkey[w] = L.r.chi[q];
+                sh.winkey[w] = chi[q];
                 sh.winh[w] = hc[q];
                 w++;
             }
@@ -83,33 +111,38 @@ __device__ __forceinline__ bool ln_expand(const SparseModel &M, LeanShared &sh, 
         const bool isfree = (freemask >> lane) & 1ull;
         const int frank = __popcll(freemask & ((1ull << lane) - 1ull));
         if (isfree && frank < total) {
-            const uint32_t key = sh.winkey[frank];
+            r.key = sh.winkey[frank];
             sh.hval[sh.winh[frank]] = (uint8_t)lane;
-            L.id = key;
-            L.r = M.fadj[key];
-            L.pm = L.pi = L.pd = 0.0;
-            L.m = L.i = L.d = 0.0;
         }
     }
     __syncthreads();
-    unsigned long long mine = 0ull;
-#pragma unroll
-    for (int q = 0; q < ADJ_DEG; q++)
-        if (insrc && q < (int)L.r.nchi) mine |= 1ull << sh.hval[hc[q]];
-    // OR over the wave
-    unsigned int lo = (unsigned int)mine, hi = (unsigned int)(mine >> 32);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        lo |= (unsigned int)__shfl_xor((int)lo, off);
-        hi |= (unsigned int)__shfl_xor((int)hi, off);
-    }
-    out = ((unsigned long long)hi << 32) | lo;
-    return true;
+    return r;
 }
 
-__device__ __forceinline__ void ln_links(const LeanShared &sh, LeanLane &L) {
-#pragma unroll
-    for (int q = 0; q < ADJ_DEG; q++) L.pl[q] = (L.id != LN_EMPTY && q < (int)L.r.npar) ? ln_find(sh, L.r.par[q]) : -1;
+// Children of the nodes on the lanes of `src`: lanes that hold them are returned as a mask; children
+// that are not in the frontier yet take free lanes (their records are fetched).  Returns false when
+// the free lanes do not suffice (the caller abandons the column).
+__device__ __forceinline__ bool ln_expand(const SparseModel &M, LeanShared &sh, LeanLane &L, unsigned long long src,
+                                           unsigned long long &out, int &inserted) {
+    const int lane = threadIdx.x;
+    const bool insrc = (src >> lane) & 1ull;
+    inserted = 0;
+    // the common case on a unitig: every child is in the frontier already (links resolved once per step)
+    if (__ballot(insrc && L.miss) != 0ull) {
+        const LnAdopt ad = ln_insert_children(sh, insrc, L.id != LN_EMPTY, L.r.chi[0], L.r.chi[1], L.r.chi[2], L.r.chi[3],
+                                              L.r.chi[4], (int)L.r.nchi);
+        if (ad.total < 0) return false;
+        inserted = ad.total;
+        if (ad.key != LN_EMPTY) {
+            L.id = ad.key;
+            L.r = M.fadj[ad.key];
+            L.pm = L.pi = L.pd = 0.0;
+            L.m = L.i = L.d = 0.0;
+        }
+        ln_links(sh, L);  // new nodes: their own links and everybody's links to them
+    }
+    out = ln_children_of(L, src);
+    return true;
 }
 
 __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a) {
@@ -166,67 +199,83 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
     double ibs = (!err && pos < end) ? exp(a.M.logib[pos - 1] - (double)E * SP_LN2) : 0.0;
     uint8_t xn = (!err && pos < end) ? a.bases[((size_t)g * a.Lb + pos) * a.W + r] : (uint8_t)0;
 
+#ifdef PHMM_LEAN_PROF
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = 0;
+    int psteps = 0, plev = 0;
+#define PROF_T(k)                         \
+    {                                     \
+        const long long now_ = clock64(); \
+        pt[k] += now_ - pc0;              \
+        pc0 = now_;                       \
+    }
+#else
+#define PROF_T(k)
+#endif
     for (; pos < end && !err; pos++) {
+#ifdef PHMM_LEAN_PROF
+        pc0 = clock64();
+        psteps++;
+#endif
         const uint8_t x = xn;
         if (pos + 1 < end) xn = a.bases[((size_t)g * a.Lb + pos + 1) * a.W + r];
         // ---- node -> lane map of the resident nodes (previous column)
         ln_rebuild(sh, L.id);
+        ln_links(sh, L);
         // ---- top = previous nodes within the ratio of the best total (table.rs:134-149)
         const double t = L.id != LN_EMPTY ? L.pm + L.pi + L.pd : 0.0;
         const double tmax = wave_max(t);
         const unsigned long long top = __ballot(t > 0.0 && t > tmax * a.ratio_lin);
-        // ---- active = top ++ children(top)
-        unsigned long long kids = 0ull;
-        int ins = 0;
-        if (!ln_expand(a.M, sh, L, top, kids, ins)) {
-            err |= SP_ERR_CAPACITY;
-            break;
-        }
-        act = top | kids;
-        const bool is_act = (act >> lane) & 1ull;
-        ln_links(sh, L);
-        // ---- fm, fi (forward.rs:337-388)
+        PROF_T(0)
+        // ---- one loop over the expansions of the step (a single copy of the insertion path keeps the kernel
+        // at 4 waves per SIMD): h = 0 gives active = top ++ children(top) and m, i; h = 1 .. n_max_gaps + 1 the
+        // adaptive fd levels S_0 = children(active), S_t = children(S_{t-1}) (forward.rs:423-524)
         const double c_begin = lp.p_IM * ibs;                 // p_MM*mb' + p_IM*ib' with mb' = 0
         const double ib_cur = lp.p_random * lp.p_II * ibs;    // fib
         const double c_del = lp.p_ID * ib_cur;                // fd0 from_begin with mb = 0
-        const double G = lp.p_MM * L.pm + lp.p_IM * L.pi + lp.p_DM * L.pd;
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < ADJ_DEG; q++) {
-            const double v = ln_shfl(G, L.pl[q]);
-            if (is_act && q < (int)L.r.npar && L.pl[q] >= 0) acc += L.r.par_w[q] * v;
-        }
-        L.m = L.i = L.d = 0.0;
-        if (is_act) {
-            const double pe = L.r.emis == x ? lp.p_match : lp.p_mismatch;
-            L.m = pe * (acc + L.r.init * c_begin);
-            L.i = lp.p_random * (lp.p_MI * L.pm + lp.p_II * L.pi + lp.p_DI * L.pd);
-        }
-        // The previous column's values are not needed any more.  When lanes are short, the previous-only
-        // nodes leave now instead of at the end of the step (one that comes back as a Del-level node is
-        // fetched again), so that a wide frontier still fits the 64 lanes.
-        {
-            const unsigned long long resident = __ballot(L.id != LN_EMPTY);
-            if (64 - __popcll(resident) < 16 && (resident & ~act) != 0ull) {
-                if (!is_act) {
-                    L.id = LN_EMPTY;
-                    L.pm = L.pi = L.pd = 0.0;
-                }
-                ln_rebuild(sh, L.id);
-                ln_links(sh, L);
-            }
-        }
-        // ---- adaptive fd (forward.rs:423-524)
-        unsigned long long members = act, srcm = act;
-        double lv = lp.p_MD * L.m + lp.p_ID * L.i;  // level value handed to the next level
+        unsigned long long members = 0ull, srcm = top;
+        double lv = 0.0;  // level value handed to the next level
         bool overflow = false;
-        for (int lvl = 0; lvl <= lp.n_max_gaps; lvl++) {
+        int ins = 0;
+        L.m = L.i = L.d = 0.0;
+        for (int h = 0; h <= lp.n_max_gaps + 1; h++) {
             unsigned long long S = 0ull;
             if (!ln_expand(a.M, sh, L, srcm, S, ins)) {
                 overflow = true;
                 break;
             }
-            if (ins > 0) ln_links(sh, L);
+            if (h == 0) {
+                act = top | S;
+                const bool is_act = (act >> lane) & 1ull;
+                // fm, fi (forward.rs:337-388)
+                const double G = lp.p_MM * L.pm + lp.p_IM * L.pi + lp.p_DM * L.pd;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < ADJ_DEG; q++) {
+                    const double v = ln_shfl(G, L.pl[q]);
+                    if (is_act && q < (int)L.r.npar && L.pl[q] >= 0) acc += L.r.par_w[q] * v;
+                }
+                if (is_act) {
+                    const double pe = L.r.emis == x ? lp.p_match : lp.p_mismatch;
+                    L.m = pe * (acc + L.r.init * c_begin);
+                    L.i = lp.p_random * (lp.p_MI * L.pm + lp.p_II * L.pi + lp.p_DI * L.pd);
+                }
+                // The previous column's values are not needed any more.  When lanes are short, the previous-only
+                // nodes leave now instead of at the end of the step (one that comes back as a Del-level node is
+                // fetched again), so that a wide frontier still fits the 64 lanes.
+                const unsigned long long resident = __ballot(L.id != LN_EMPTY);
+                if (64 - __popcll(resident) < 16 && (resident & ~act) != 0ull) {
+                    if (!is_act) {
+                        L.id = LN_EMPTY;
+                        L.pm = L.pi = L.pd = 0.0;
+                    }
+                    ln_rebuild(sh, L.id);
+                    ln_links(sh, L);
+                }
+                members = act;
+                srcm = act;
+                lv = lp.p_MD * L.m + lp.p_ID * L.i;
+                continue;
+            }
             const bool inS = (S >> lane) & 1ull;
             double s = 0.0;
 #pragma unroll
@@ -234,13 +283,14 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
                 const double v = ln_shfl(lv, L.pl[q]);
                 if (inS && q < (int)L.r.npar && L.pl[q] >= 0 && ((srcm >> L.pl[q]) & 1ull)) s += L.r.par_w[q] * v;
             }
-            const double val = lvl == 0 ? s + L.r.init * c_del : lp.p_DD * s;
+            const double val = h == 1 ? s + L.r.init * c_del : lp.p_DD * s;
             if (inS) L.d += val;
             lv = inS ? val : 0.0;
             srcm = S;
             members |= S;
             if (S == 0ull) break;
         }
+        PROF_T(4)
         if (overflow) {
             err |= SP_ERR_CAPACITY;
             break;
@@ -256,6 +306,7 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
         L.d *= sc;
         E += e;
         ibs = ib_cur * sc;
+        PROF_T(5)
         // ---- store the column: active entries first, then the Del-only ones
         {
             const int na = __popcll(act);
@@ -305,7 +356,14 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
             L.pm = L.pi = L.pd = 0.0;
         }
         done_to = pos + 1;
+        PROF_T(6)
     }
+#ifdef PHMM_LEAN_PROF
+    if (blockIdx.x == 0 && lane == 0 && psteps > 0)
+        printf("lean_fwd prof: steps %d levels %d | rebuild+top %lld expand %lld links+fm %lld compact %lld del %lld rescale %lld store %lld (cycles/step)\n",
+               psteps, plev, pt[0] / psteps, pt[1] / psteps, pt[2] / psteps, pt[3] / psteps, pt[4] / psteps, pt[5] / psteps,
+               pt[6] / psteps);
+#endif
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
     const bool finished = !err && done_to >= len;
     double lpv = NAN;
