@@ -207,7 +207,23 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
     }
     uint8_t xn = (!stopped && !err && pos >= s0 + 1) ? a.bases[((size_t)g * a.Lb + pos) * a.W + r] : (uint8_t)0;
 
+#ifdef PHMM_LEAN_PROF
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = 0;
+    int psteps = 0;
+#define PROFB_T(k)                        \
+    {                                     \
+        const long long now_ = clock64(); \
+        pt[k] += now_ - pc0;              \
+        pc0 = now_;                       \
+    }
+#else
+#define PROFB_T(k)
+#endif
     for (; !stopped && pos >= s0 + 1 && !err; pos--) {
+#ifdef PHMM_LEAN_PROF
+        pc0 = clock64();
+        psteps++;
+#endif
         const uint8_t x = xn;
         if (pos - 1 >= s0 + 1) xn = a.bases[((size_t)g * a.Lb + pos - 1) * a.W + r];
         // this position's record is (hcur, ecur); start the next one's arrays and the header after it
@@ -219,6 +235,7 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
             break;
         }
         const int n = hcur.n, na = hcur.na < hcur.n ? hcur.na : hcur.n;
+        PROFB_T(0)
         // ---- route the entries to the lanes of their nodes
         ln_rebuild(sh.h, id);
         const bool has_e = lane < n;
@@ -251,6 +268,7 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
         if (has_e) sh.slot_of[tl] = (uint8_t)lane;
         __syncthreads();
         const int slot = sh.slot_of[lane] == 0xff ? -1 : (int)sh.slot_of[lane];
+        PROFB_T(1)
         double fm = 0.0, fi = 0.0, fd = 0.0;
         bool sel = false;  // member of the B list: one of the `na` largest totals (ties: record order)
         if (slot >= 0) {
@@ -284,12 +302,14 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
             }
         }
         __syncthreads();
+        PROFB_T(2)
         // ---- child links
         int cl[ADJ_DEG];
 #pragma unroll
         for (int q = 0; q < ADJ_DEG; q++) cl[q] = (sel && q < (int)R.nchi) ? ln_find(sh.h, R.chi[q]) : -1;
         const unsigned long long selm = __ballot(sel);
         const unsigned long long prevm = __ballot(inprev);
+        PROFB_T(3)
         // ---- bd0 (backward.rs:354-377)
         const double pend = lp.p_end;
         double a1 = 0.0;
@@ -329,6 +349,7 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
         double bm = sel ? lp.p_MM * a1 + lp.p_MD * td + lp.p_MI * qq : 0.0;
         double bi = sel ? lp.p_IM * a1 + lp.p_ID * td + lp.p_II * qq : 0.0;
         double bd = dsum;
+        PROFB_T(4)
         // ---- rescale
         double mx = wave_max(fmax(fmax(bm, bi), bd));
         const int e = sp_exp_of(mx);
@@ -340,6 +361,7 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
         // ---- S = F.tables[pos-1] (.) B.tables[pos] / P over F's elements, then the mapping of pos-1
         const double w = ok ? exp((double)(hcur.E + Ecur) * SP_LN2 - logP) : 0.0;
         const double val = (slot >= 0 && sel) ? w * (fm * bm + fi * bi + fd * bd) : 0.0;
+        PROFB_T(5)
         if (!emit(q0 + (uint64_t)(pos - 1), slot >= 0, id, val, slot)) {
             err |= SP_ERR_POOL;
             break;
@@ -361,7 +383,14 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
         hcur = hnext;
         ecur = enext;
         hnext = hnn;
+        PROFB_T(6)
     }
+#ifdef PHMM_LEAN_PROF
+    if (blockIdx.x == 0 && lane == 0 && psteps > 0)
+        printf("lean_bwd prof: steps %d | loads %lld rebuild+route %lld select+insert %lld links %lld bd+bm %lld rescale %lld emit %lld (cycles/step)\n",
+               psteps, pt[0] / psteps, pt[1] / psteps, pt[2] / psteps, pt[3] / psteps, pt[4] / psteps, pt[5] / psteps,
+               pt[6] / psteps);
+#endif
     // ---- leave: park the column for the next phase, or hand it to the dense backward kernel
     if (stopped && !err) {
         if (have_col && stop_at < len) lb_park(a, gi, inprev, id, pm, pi, pd, Eprev);

@@ -75,31 +75,60 @@ template <int CAP> __device__ __forceinline__ int hash_find(const Col<CAP> &c, u
     }
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+// Cross-lane reductions of a FULL wave64 (every caller is a 64-thread block with all lanes active) on the DPP
+// path: row_shr 1, 2, 4, 8 gives the inclusive scan inside each row of 16 lanes, row_bcast15 / row_bcast31
+// carry it across the rows, lane 63 then holds the total.  Six VALU steps instead of six dependent
+// ds_bpermute round trips (~100+ cycles each); the frontier kernels do several of these per read position.
+// Lanes a DPP step cannot read (bound_ctrl = 0) take `ident`.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_i(int ident, int v) {
+    return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_d(double ident, double v) {
+    const long long iv = __double_as_longlong(v), ii = __double_as_longlong(ident);
+    const int lo = dpp_i<CTRL, ROW_MASK>((int)(ii & 0xffffffffll), (int)(iv & 0xffffffffll));
+    const int hi = dpp_i<CTRL, ROW_MASK>((int)(ii >> 32), (int)(iv >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+static constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118,
+                     DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+__device__ __forceinline__ double wave_bcast63(double v) {
+    const long long iv = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(iv & 0xffffffffll), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(iv >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+// inclusive scans (sum); the reductions are their last lane
+__device__ __forceinline__ double wave_scan_sum(double v) {
+    v += dpp_d<DPP_ROW_SHR1, 0xf>(0.0, v);
+    v += dpp_d<DPP_ROW_SHR2, 0xf>(0.0, v);
+    v += dpp_d<DPP_ROW_SHR4, 0xf>(0.0, v);
+    v += dpp_d<DPP_ROW_SHR8, 0xf>(0.0, v);
+    v += dpp_d<DPP_ROW_BCAST15, 0xa>(0.0, v);
+    v += dpp_d<DPP_ROW_BCAST31, 0xc>(0.0, v);
     return v;
 }
+__device__ __forceinline__ double wave_sum(double v) { return wave_bcast63(wave_scan_sum(v)); }
+// maximum of NON-NEGATIVE values (identity 0): what every caller has (probabilities, totals)
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ int wave_isum(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v = fmax(v, dpp_d<DPP_ROW_SHR1, 0xf>(0.0, v));
+    v = fmax(v, dpp_d<DPP_ROW_SHR2, 0xf>(0.0, v));
+    v = fmax(v, dpp_d<DPP_ROW_SHR4, 0xf>(0.0, v));
+    v = fmax(v, dpp_d<DPP_ROW_SHR8, 0xf>(0.0, v));
+    v = fmax(v, dpp_d<DPP_ROW_BCAST15, 0xa>(0.0, v));
+    v = fmax(v, dpp_d<DPP_ROW_BCAST31, 0xc>(0.0, v));
+    return wave_bcast63(v);
 }
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ int wave_iscan(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(v, off);
-        if (lane >= off) v += t;
-    }
+    v += dpp_i<DPP_ROW_SHR1, 0xf>(0, v);
+    v += dpp_i<DPP_ROW_SHR2, 0xf>(0, v);
+    v += dpp_i<DPP_ROW_SHR4, 0xf>(0, v);
+    v += dpp_i<DPP_ROW_SHR8, 0xf>(0, v);
+    v += dpp_i<DPP_ROW_BCAST15, 0xa>(0, v);
+    v += dpp_i<DPP_ROW_BCAST31, 0xc>(0, v);
     return v;
 }
+__device__ __forceinline__ int wave_isum(int v) { return __builtin_amdgcn_readlane(wave_iscan(v), 63); }
 
 __device__ __forceinline__ int sp_exp_of(double v) {  // v*2^-e in [0.5,1); 0 for v == 0
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
