@@ -50,7 +50,7 @@ __device__ __forceinline__ void lb_park(const SparseBwdArgs &a, uint32_t gi, boo
     }
 }
 
-__global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a) {
+__global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArgs a) {
     __shared__ LeanBwdShared sh;
     const int lane = threadIdx.x;
     const uint32_t gi = a.lanes[blockIdx.x];
@@ -62,6 +62,8 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
     const double logP = a.d.logPf[gi];
     const LinParams &lp = a.M.lp;
     const bool ok = logP > -INFINITY;
+    const int kP = ok ? (int)rint(-logP / SP_LN2) : 0;
+    const double cP = ok ? exp(-logP - (double)kP * SP_LN2) : 0.0;
     uint32_t err = 0;
 
     // ---- lane state: node, record, B values of the column of position pos+1
@@ -101,11 +103,15 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
         const int k = __popcll(km);
         int rank = 0;
         unsigned long long mm = km;
+        const long long vb = __double_as_longlong(v);
         while (mm) {
-            const int l = __ffsll((long long)mm) - 1;
+            // (l is wave-uniform: scalar lane reads instead of ds_bpermute round trips)
+            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
             mm &= mm - 1ull;
-            const double u = __shfl(v, l);
-            const int us = __shfl(slot, l);
+            const int ulo = __builtin_amdgcn_readlane((int)(vb & 0xffffffffll), l);
+            const int uhi = __builtin_amdgcn_readlane((int)(vb >> 32), l);
+            const double u = __longlong_as_double(((long long)uhi << 32) | (long long)(unsigned int)ulo);
+            const int us = __builtin_amdgcn_readlane(slot, l);
             rank += (u > v) || (u == v && us < slot);
         }
         const uint64_t idb = (uint64_t)((k + 1) & ~1) * 4;
@@ -294,9 +300,12 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
             else {
                 const double t = sh.etot[slot];
                 int rank = 0;
-                for (int j = 0; j < n; j++) {
-                    const double u = sh.etot[j];
-                    rank += (u > t) || (u == t && j < slot);
+                for (int j0 = 0; j0 < n; j0 += 8) {  // (eight LDS reads in flight; etot has 64 entries)
+                    double u[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) u[q] = sh.etot[(j0 + q) & 63];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) rank += (j0 + q < n) && ((u[q] > t) || (u[q] == t && j0 + q < slot));
                 }
                 sel = rank < na;
             }
@@ -359,7 +368,9 @@ __global__ void __launch_bounds__(64) lean_backward_kernel(const SparseBwdArgs a
         bd *= sc;
         const int Ecur = (prev_is_init ? 0 : Eprev) + e;
         // ---- S = F.tables[pos-1] (.) B.tables[pos] / P over F's elements, then the mapping of pos-1
-        const double w = ok ? exp((double)(hcur.E + Ecur) * SP_LN2 - logP) : 0.0;
+        // 2^(E_F + E_B) / P with P = 2^-kP e^-rP split once per read: a power of two per position, no exp
+        const int ew = hcur.E + Ecur + kP;
+        const double w = !ok ? 0.0 : ((ew > -1000 && ew < 1000) ? cP * sp_pow2(ew) : exp((double)(hcur.E + Ecur) * SP_LN2 - logP));
         const double val = (slot >= 0 && sel) ? w * (fm * bm + fi * bi + fd * bd) : 0.0;
         PROFB_T(5)
         if (!emit(q0 + (uint64_t)(pos - 1), slot >= 0, id, val, slot)) {
