@@ -270,9 +270,9 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
             sh.tgt[lane] = (uint8_t)tl;
         }
         sh.slot_of[lane] = 0xff;
-        __syncthreads();
+        ln_sync();
         if (has_e) sh.slot_of[tl] = (uint8_t)lane;
-        __syncthreads();
+        ln_sync();
         const int slot = sh.slot_of[lane] == 0xff ? -1 : (int)sh.slot_of[lane];
         PROFB_T(1)
         double fm = 0.0, fi = 0.0, fd = 0.0;
@@ -290,11 +290,11 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
                 // make it findable for the child links below
                 uint32_t h = ln_hash(id);
                 for (;;) {
-                    const uint32_t old = atomicCAS(&sh.h.hkey[h], LN_EMPTY, id);
+                    const uint32_t old = atomicCAS(&sh.h.ent[h].x, LN_EMPTY, id);
                     if (old == LN_EMPTY) break;
                     h = (h + 1) & (LN_HASH - 1);
                 }
-                sh.h.hval[h] = (uint8_t)lane;
+                sh.h.ent[h].y = (uint32_t)lane;
             }
             if (na >= n) sel = true;
             else {
@@ -310,12 +310,20 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
                 sel = rank < na;
             }
         }
-        __syncthreads();
+        ln_sync();
         PROFB_T(2)
         // ---- child links
         int cl[ADJ_DEG];
+        {
+            uint32_t ck[ADJ_DEG];
+            bool cv[ADJ_DEG];
 #pragma unroll
-        for (int q = 0; q < ADJ_DEG; q++) cl[q] = (sel && q < (int)R.nchi) ? ln_find(sh.h, R.chi[q]) : -1;
+            for (int q = 0; q < ADJ_DEG; q++) {
+                ck[q] = R.chi[q];
+                cv[q] = sel && q < (int)R.nchi;
+            }
+            ln_find_many<ADJ_DEG>(sh.h, ck, cv, cl);
+        }
         const unsigned long long selm = __ballot(sel);
         const unsigned long long prevm = __ballot(inprev);
         PROFB_T(3)

@@ -11,12 +11,21 @@ static constexpr int LN_HASH = 256;
 static constexpr uint64_t LN_SLAB = 32768;  // record-pool bytes claimed per atomic
 
 struct LeanShared {
-    uint32_t hkey[LN_HASH];
-    uint8_t hval[LN_HASH];
+    uint2 ent[LN_HASH];  // {node, lane}: one 8-byte LDS read answers a lookup
+
     uint32_t winkey[64];
     uint16_t winh[64];
     unsigned long long mark;
 };
+
+// Ordering point between LDS accesses of the ONE wave of a block.  The LDS executes a wave's instructions in
+// issue order, so lanes see each other's earlier writes without a barrier; what is needed is that the compiler
+// keeps the order.  __syncthreads() would add s_waitcnt vmcnt(0) -- every outstanding global load and store
+// of the wave (record stores, record fetches) would be waited for at each of the ~10 sync points of a position.
+__device__ __forceinline__ void ln_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ uint32_t ln_hash(uint32_t id) { return (id * 2654435761u) >> 24; }
 
@@ -24,10 +33,39 @@ __device__ __forceinline__ uint32_t ln_hash(uint32_t id) { return (id * 26544357
 __device__ __forceinline__ int ln_find(const LeanShared &sh, uint32_t id) {
     uint32_t h = ln_hash(id);
     for (;;) {
-        const uint32_t k = sh.hkey[h];
-        if (k == id) return (int)sh.hval[h];
-        if (k == LN_EMPTY) return -1;
+        const uint2 e = sh.ent[h];
+        if (e.x == id) return (int)e.y;
+        if (e.x == LN_EMPTY) return -1;
         h = (h + 1) & (LN_HASH - 1);
+    }
+}
+
+// Lanes of K nodes at once (valid[q] false: -1).  The first probes of all K keys are in flight together -- at a
+// load of at most 64 keys in 256 cells nearly every lookup ends there; the rest walks on one by one.
+template <int K> __device__ __forceinline__ void ln_find_many(const LeanShared &sh, const uint32_t (&key)[K], const bool (&valid)[K],
+                                                              int (&out)[K]) {
+    uint2 e[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) e[q] = sh.ent[ln_hash(key[q])];
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        int r = -1;
+        if (valid[q]) {
+            if (e[q].x == key[q]) r = (int)e[q].y;
+            else if (e[q].x != LN_EMPTY) {
+                uint32_t h = (ln_hash(key[q]) + 1) & (LN_HASH - 1);
+                for (;;) {
+                    const uint2 f = sh.ent[h];
+                    if (f.x == key[q]) {
+                        r = (int)f.y;
+                        break;
+                    }
+                    if (f.x == LN_EMPTY) break;
+                    h = (h + 1) & (LN_HASH - 1);
+                }
+            }
+        }
+        out[q] = r;
     }
 }
 
@@ -39,18 +77,18 @@ __device__ __forceinline__ double ln_shfl(double v, int src) {
 
 // (re)build the map from the nodes currently on the lanes
 __device__ __forceinline__ void ln_rebuild(LeanShared &sh, uint32_t id) {
-    for (int h = threadIdx.x; h < LN_HASH; h += 64) sh.hkey[h] = LN_EMPTY;
-    __syncthreads();
+    for (int h = threadIdx.x; h < LN_HASH; h += 64) sh.ent[h].x = LN_EMPTY;
+    ln_sync();
     if (id != LN_EMPTY) {
         uint32_t h = ln_hash(id);
         for (;;) {
-            const uint32_t old = atomicCAS(&sh.hkey[h], LN_EMPTY, id);
+            const uint32_t old = atomicCAS(&sh.ent[h].x, LN_EMPTY, id);
             if (old == LN_EMPTY) break;
             h = (h + 1) & (LN_HASH - 1);
         }
-        sh.hval[h] = (uint8_t)threadIdx.x;
+        sh.ent[h].y = threadIdx.x;
     }
-    __syncthreads();
+    ln_sync();
 }
 
 }  // namespace phmm

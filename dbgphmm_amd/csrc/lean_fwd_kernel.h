@@ -40,11 +40,25 @@ struct LeanLane {
 // the free lanes do not suffice (nothing is modified in that case except hash cells of the keys that
 // could not be placed -- the caller abandons the column).
 __device__ __forceinline__ void ln_links(const LeanShared &sh, LeanLane &L) {
+    // parents and children in one batch of lookups
+    uint32_t key[2 * ADJ_DEG];
+    bool valid[2 * ADJ_DEG];
+    int res[2 * ADJ_DEG];
+    const bool live = L.id != LN_EMPTY;
 #pragma unroll
-    for (int q = 0; q < ADJ_DEG; q++) L.pl[q] = (L.id != LN_EMPTY && q < (int)L.r.npar) ? ln_find(sh, L.r.par[q]) : -1;
+    for (int q = 0; q < ADJ_DEG; q++) {
+        key[q] = L.r.par[q];
+        valid[q] = live && q < (int)L.r.npar;
+        key[ADJ_DEG + q] = L.r.chi[q];
+        valid[ADJ_DEG + q] = live && q < (int)L.r.nchi;
+    }
+    ln_find_many<2 * ADJ_DEG>(sh, key, valid, res);
     bool miss = false;
 #pragma unroll
-    for (int q = 0; q < ADJ_DEG; q++) miss |= L.id != LN_EMPTY && q < (int)L.r.nchi && ln_find(sh, L.r.chi[q]) < 0;
+    for (int q = 0; q < ADJ_DEG; q++) {
+        L.pl[q] = res[q];
+        miss |= valid[ADJ_DEG + q] && res[ADJ_DEG + q] < 0;
+    }
     L.miss = miss;
 }
 
@@ -77,7 +91,7 @@ __device__ __noinline__ LnAdopt ln_insert_children(LeanShared &sh, bool insrc, b
             const uint32_t key = chi[q];
             uint32_t h = ln_hash(key);
             for (;;) {
-                const uint32_t old = atomicCAS(&sh.hkey[h], LN_EMPTY, key);
+                const uint32_t old = atomicCAS(&sh.ent[h].x, LN_EMPTY, key);
                 if (old == LN_EMPTY) {
                     wins |= 1u << q;
                     break;
@@ -107,15 +121,15 @@ __device__ __noinline__ LnAdopt ln_insert_children(LeanShared &sh, bool insrc, b
                 sh.winh[w] = hc[q];
                 w++;
             }
-        __syncthreads();
+        ln_sync();
         const bool isfree = (freemask >> lane) & 1ull;
         const int frank = __popcll(freemask & ((1ull << lane) - 1ull));
         if (isfree && frank < total) {
             r.key = sh.winkey[frank];
-            sh.hval[sh.winh[frank]] = (uint8_t)lane;
+            sh.ent[sh.winh[frank]].y = (uint32_t)lane;
         }
     }
-    __syncthreads();
+    ln_sync();
     return r;
 }
 
@@ -243,6 +257,10 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
                 overflow = true;
                 break;
             }
+#ifdef PHMM_LEAN_PROF
+            if (ins > 0) plev++;
+#endif
+            PROF_T(1)
             if (h == 0) {
                 act = top | S;
                 const bool is_act = (act >> lane) & 1ull;
@@ -274,6 +292,7 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
                 members = act;
                 srcm = act;
                 lv = lp.p_MD * L.m + lp.p_ID * L.i;
+                PROF_T(2)
                 continue;
             }
             const bool inS = (S >> lane) & 1ull;
@@ -288,9 +307,9 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
             lv = inS ? val : 0.0;
             srcm = S;
             members |= S;
+            PROF_T(4)
             if (S == 0ull) break;
         }
-        PROF_T(4)
         if (overflow) {
             err |= SP_ERR_CAPACITY;
             break;
@@ -360,7 +379,7 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
     }
 #ifdef PHMM_LEAN_PROF
     if (blockIdx.x == 0 && lane == 0 && psteps > 0)
-        printf("lean_fwd prof: steps %d levels %d | rebuild+top %lld expand %lld links+fm %lld compact %lld del %lld rescale %lld store %lld (cycles/step)\n",
+        printf("lean_fwd prof: steps %d insertions %d | rebuild+top %lld expand %lld links+fm %lld compact %lld del %lld rescale %lld store %lld (cycles/step)\n",
                psteps, plev, pt[0] / psteps, pt[1] / psteps, pt[2] / psteps, pt[3] / psteps, pt[4] / psteps, pt[5] / psteps,
                pt[6] / psteps);
 #endif
