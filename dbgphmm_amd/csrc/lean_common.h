@@ -12,10 +12,8 @@ static constexpr uint64_t LN_SLAB = 32768;  // record-pool bytes claimed per ato
 
 struct LeanShared {
     uint2 ent[LN_HASH];  // {node, lane}: one 8-byte LDS read answers a lookup
-
-    uint32_t winkey[64];
+    uint32_t winkey[64];  // insertion queue: new nodes and their hash cells
     uint16_t winh[64];
-    unsigned long long mark;
 };
 
 // Ordering point between LDS accesses of the ONE wave of a block.  The LDS executes a wave's instructions in

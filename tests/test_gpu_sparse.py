@@ -612,3 +612,67 @@ def test_run_sparse_node_freqs_match_oracle(gpu_lib, oracle, cfg):
         onf += one
     assert np.max(np.abs(nf - onf)) < 1e-9 * len(reads), np.abs(nf - onf).max()
     assert abs(nf.sum() - sum(map(len, reads))) < 0.02 * sum(map(len, reads))
+
+
+def _hub_graph(seed=11, fan=7, backbone=260, branch=18):
+    """A backbone with a hub: node 60 branches into `fan` arms of `branch` nodes that rejoin at one node, so that
+    one node has `fan` children and another `fan` parents (more than the 5 the packed frontier records hold:
+    the one-lane-per-node kernels step aside for the generic vector kernels)."""
+    rng = np.random.default_rng(seed)
+    bases, src, dst = [], [], []
+
+    def add(b):
+        bases.append(b)
+        return len(bases) - 1
+
+    prev = None
+    hub = join = None
+    for k in range(backbone):
+        v = add(int(rng.choice(list(b"ACGT"))))
+        if prev is not None:
+            src.append(prev)
+            dst.append(v)
+        prev = v
+        if k == 60:
+            hub = v
+            ends = []
+            for _ in range(fan):
+                p = hub
+                for _ in range(branch):
+                    w = add(int(rng.choice(list(b"ACGT"))))
+                    src.append(p)
+                    dst.append(w)
+                    p = w
+                ends.append(p)
+            join = add(int(rng.choice(list(b"ACGT"))))
+            for e in ends:
+                src.append(e)
+                dst.append(join)
+            prev = join
+    n = len(bases)
+    return D.SeqGraph(np.ones(n, dtype=np.int64), np.array(bases, dtype=np.uint8), np.array(src, dtype=np.uint32),
+                      np.array(dst, dtype=np.uint32), None)
+
+
+@pytest.mark.parametrize("no_lean", [False, True])
+def test_generic_frontier_class_matches_oracle(gpu_lib, oracle, no_lean, monkeypatch):
+    """The generic vector kernels of the <= 64 / 128-node class (sparse_forward_kernel<128>, sparse_backward_kernel<64>)
+    only run where the one-lane-per-node kernels cannot: nodes of degree above 5, or PHMM_NO_LEAN.  Both ways
+    must give the oracle's scores, mapping lists and node usage."""
+    if no_lean:
+        monkeypatch.setenv("PHMM_NO_LEAN", "1")
+        arrays, sg = small_dbg_model(600, 12, 0.01, seed=3, min_copy_num=1)
+    else:
+        sg = _hub_graph()
+        arrays = D.vectorised_to_phmm(sg, D.PHMMParams.uniform(0.01).with_(n_warmup=12), 1)
+    reads = D.sample_reads(arrays, 10 ** 9, 150, seed=4, max_reads=24)
+    reads = [r[: max(5, len(r) - (j * 7) % 60)] for j, r in enumerate(reads)]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    tot, lp = gm.to_full_prob_reads(rc, None, True)
+    olp = om.full_prob_reads(reads, None, True, n_threads=8)
+    assert np.max(np.abs(lp - olp)) < 1e-6
+    mp, nf = gm.generate_mappings(rc, None, True)
+    omp, onf = om.generate_mappings(reads, None, True, n_threads=8)
+    _compare_mappings(reads, mp.arrays(), omp)
+    assert np.max(np.abs(nf - onf)) < 1e-6 * len(reads)
