@@ -118,7 +118,7 @@ __device__ void append_neighbours(const SparseModel &M, bool children, FVec<CAP>
         running += __shfl(inc, 63);
     }
     if (lane == 0) sc.pref[nsrc] = (uint32_t)running;
-    __syncthreads();
+    wave_sync();
     const int total = running;
     int nl = lvl_list ? *lvl_n : 0;
     for (int cbase = 0; cbase < total; cbase += 64) {
@@ -146,9 +146,9 @@ __device__ void append_neighbours(const SparseModel &M, bool children, FVec<CAP>
             }
             if (valid) sc.arb[cell] = 0xffffffffu;
         }
-        __syncthreads();
+        wave_sync();
         if (valid) atomicMin(&sc.arb[cell], (uint32_t)lane);
-        __syncthreads();
+        wave_sync();
         const bool winner = valid && sc.arb[cell] == (uint32_t)lane;
         int slot = winner ? (int)v.hslot[cell] : -2;
         const bool is_new = winner && slot == (int)SLOT_NONE;
@@ -170,7 +170,7 @@ __device__ void append_neighbours(const SparseModel &M, bool children, FVec<CAP>
                 slot = -1;  // dropped (the cell keeps SLOT_NONE: later lookups miss)
             }
         }
-        __syncthreads();
+        wave_sync();
         if (lane == 0) {
             const int add = __popcll(newmask);
             v.n = n0 + add > CAP ? CAP : n0 + add;
@@ -186,10 +186,10 @@ __device__ void append_neighbours(const SparseModel &M, bool children, FVec<CAP>
             }
             nl += __popcll(lm);
         }
-        __syncthreads();
+        wave_sync();
     }
     if (lvl_list && lane == 0) *lvl_n = nl;
-    __syncthreads();
+    wave_sync();
 }
 
 // Where the previous column lives for the step being computed.
@@ -233,11 +233,11 @@ __device__ void fwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
     const int ntop = cur.n;
     // active = to_childs_and_us(top)  (forward.rs:147; active_nodes.rs:23-35)
     for (int j = lane; j < ntop; j += 64) sc.order[j] = (uint16_t)j;
-    __syncthreads();
+    wave_sync();
     append_neighbours<CAP>(M, true, cur, sc, sc.order, ntop, nullptr, nullptr, nullptr, 0);
     const int na = cur.n;
     if (lane == 0) cur.na = na;
-    __syncthreads();
+    wave_sync();
     // fm (forward.rs:337-359), fi (378-388), fib (541-545)
     const bool first = prev.is_init;
     const double ibs = first ? 0.0 : exp(M.logib[pos - 1] - (double)prev.E * SP_LN2);
@@ -265,10 +265,10 @@ __device__ void fwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
         sc.stb[j] = 0xff;
     }
     if (lane == 0) sc.nla = sc.nlb = 0;
-    __syncthreads();
+    wave_sync();
     // adaptive fd (forward.rs:423-466): S0 = to_childs(active), S_t = to_childs(S_{t-1})
     for (int j = lane; j < na; j += 64) sc.order[j] = (uint16_t)j;
-    __syncthreads();
+    wave_sync();
     uint16_t *src = sc.order;
     int nsrc = na;
     for (int t = 0; t <= lp.n_max_gaps; t++) {
@@ -279,7 +279,7 @@ __device__ void fwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
         double *lv_cur = (t & 1) ? sc.lvb : sc.tot;
         const double *lv_prev = (t & 1) ? sc.tot : sc.lvb;
         if (lane == 0) *ln = 0;
-        __syncthreads();
+        wave_sync();
         append_neighbours<CAP>(M, true, cur, sc, src, nsrc, lst, ln, st_cur, (uint8_t)t);
         const int nl = *ln;
         for (int j = lane; j < nl; j += 64) {
@@ -301,7 +301,7 @@ __device__ void fwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
             lv_cur[s] = val;
             cur.d[s] += val;
         }
-        __syncthreads();
+        wave_sync();
         src = lst;
         nsrc = nl;
     }
@@ -317,7 +317,7 @@ __device__ void fwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
         cur.d[j] *= s;
     }
     if (lane == 0) cur.E = prev.E + e;
-    __syncthreads();
+    wave_sync();
 }
 
 // top_nodes_by_score_ratio / top_nodes of a sparse column (table.rs:127-149) written as the
@@ -330,9 +330,9 @@ __device__ void select_top(const FVec<CAP> &prev, FVec<CAP> &cur, FScratch<CAP> 
     const int n = prev.n;
     fv_clear(cur);
     for (int j = lane; j < n; j += 64) sc.tot[j] = prev.m[j] + prev.i[j] + prev.d[j];
-    __syncthreads();
+    wave_sync();
     sort_desc<CAP>(sc.tot, n, sc.order);
-    __syncthreads();
+    wave_sync();
     int ntop = 0;
     if (n > 0) {
         const double t0 = sc.tot[sc.order[0]];
@@ -352,7 +352,7 @@ __device__ void select_top(const FVec<CAP> &prev, FVec<CAP> &cur, FScratch<CAP> 
         cur.hslot[cell] = (uint16_t)j;
     }
     if (lane == 0) cur.n = ntop;
-    __syncthreads();
+    wave_sync();
 }
 
 template <int CAP> __device__ __forceinline__ double fv_log_end(const SparseModel &M, const FVec<CAP> &c) {

@@ -16,14 +16,7 @@ struct LeanShared {
     uint16_t winh[64];
 };
 
-// Ordering point between LDS accesses of the ONE wave of a block.  The LDS executes a wave's instructions in
-// issue order, so lanes see each other's earlier writes without a barrier; what is needed is that the compiler
-// keeps the order.  __syncthreads() would add s_waitcnt vmcnt(0) -- every outstanding global load and store
-// of the wave (record stores, record fetches) would be waited for at each of the ~10 sync points of a position.
-__device__ __forceinline__ void ln_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
+__device__ __forceinline__ void ln_sync() { wave_sync(); }
 
 __device__ __forceinline__ uint32_t ln_hash(uint32_t id) { return (id * 2654435761u) >> 24; }
 

@@ -52,7 +52,7 @@ template <int CAP> __device__ bool load_record(const RecPool &p, uint64_t pos_in
         f.m[j] = j < na ? m[j] : 0.0;
         f.i[j] = j < na ? i[j] : 0.0;
     }
-    __syncthreads();
+    wave_sync();
     return true;
 }
 
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
         } else {
             const double w = ok ? exp((double)fr.E * SP_LN2 - logP) * lp.p_end : 0.0;
             for (int j = lane; j < fr.n; j += 64) val[j] = w * (fr.m[j] + fr.i[j] + fr.d[j]);
-            __syncthreads();
+            wave_sync();
             if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, false, order, a.topk))
                 err |= SP_ERR_POOL;
         }
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
                 c.n = c.na = n;
                 c.E = h.E;
             }
-            __syncthreads();
+            wave_sync();
             for (int j = lane; j < n; j += 64) {
                 c.id[j] = h.id[j];
                 c.m[j] = h.m[j];
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
                 c.d[j] = h.d[j];
                 hash_insert(c, h.id[j], j);
             }
-            __syncthreads();
+            wave_sync();
             have_cols = 1;
         }
     }
@@ -180,13 +180,13 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             for (int j = lane; j < nl; j += 64) list[j] = a.list_nodes[l0 + j];
         } else {
             for (int j = lane; j < fr.n; j += 64) val[j] = fr.m[j] + fr.i[j] + fr.d[j];
-            __syncthreads();
+            wave_sync();
             sort_desc<CAP>(val, fr.n, order);
-            __syncthreads();
+            wave_sync();
             nl = fr.na < fr.n ? fr.na : fr.n;
             for (int j = lane; j < nl; j += 64) list[j] = fr.id[order[j]];
         }
-        __syncthreads();
+        wave_sync();
         Col<CAP> &prev = cols[(pos + 1) & 1];
         Col<CAP> &cur = cols[pos & 1];
         bwd_list_step<CAP>(a.M, prev, pos == len - 1, cur, list, nl, a.bases[((size_t)g * a.Lb + pos) * a.W + r], dA, dB);
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             const int bs = hash_find(cur, fr.id[j]);
             val[j] = bs >= 0 ? w * (fr.m[j] * cur.m[bs] + fr.i[j] * cur.i[bs] + fr.d[j] * cur.d[bs]) : 0.0;
         }
-        __syncthreads();
+        wave_sync();
         if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, false, order, a.topk))
             err |= SP_ERR_POOL;
     }

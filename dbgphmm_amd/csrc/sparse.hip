@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(64) hinted_score_kernel(const HintedArgs a) {
         cols[1].n = cols[1].na = 0;
         cols[1].E = 0;
     }
-    __syncthreads();
+    wave_sync();
     int pos = 0;
     for (; pos < len; pos++) {
         const uint64_t o0 = a.map_pos_off[b0 + pos], o1 = a.map_pos_off[b0 + pos + 1];

@@ -59,11 +59,11 @@ __device__ void bwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
     const int ntop = cur.n;
     // S_0 = to_parents_and_us(active)  (backward.rs:246; active_nodes.rs:48-56)
     for (int j = lane; j < ntop; j += 64) sc.order[j] = (uint16_t)j;
-    __syncthreads();
+    wave_sync();
     append_neighbours<CAP>(M, false, cur, sc, sc.order, ntop, nullptr, nullptr, nullptr, 0);
     const int na = cur.n;
     if (lane == 0) cur.na = na;
-    __syncthreads();
+    wave_sync();
     // bd0 on S_0 (backward.rs:354-377)
     for (int j = lane; j < na; j += 64) {
         const uint32_t k = cur.id[j];
@@ -82,13 +82,13 @@ __device__ void bwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
         sc.tot[j] = v;
         cur.d[j] = v;
     }
-    __syncthreads();
+    wave_sync();
     // bdt on S_t = to_parents_and_us(S_{t-1}) (backward.rs:322-340, 387-404): level values of t-1 exist on the
     // first nprev slots only
     int nprev = na;
     for (int t = 1; t <= lp.n_max_gaps; t++) {
         for (int j = lane; j < nprev; j += 64) sc.order[j] = (uint16_t)j;
-        __syncthreads();
+        wave_sync();
         append_neighbours<CAP>(M, false, cur, sc, sc.order, nprev, nullptr, nullptr, nullptr, 0);
         const int nt = cur.n;
         const double *lv_prev = (t & 1) ? sc.tot : sc.lvb;
@@ -106,7 +106,7 @@ __device__ void bwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
             lv_cur[j] = v;
             cur.d[j] += v;
         }
-        __syncthreads();
+        wave_sync();
         nprev = nt;
     }
     // bm, bi on S_0 with the finished Del column (backward.rs:423-483); bmb, bib (499-555)
@@ -137,7 +137,7 @@ __device__ void bwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
     }
     s1 = wave_sum(a1);
     s2 = wave_sum(a2);
-    __syncthreads();
+    wave_sync();
     // rescale so that the column maximum is in [0.5, 1)
     double mx = 0.0;
     for (int j = lane; j < cur.n; j += 64) mx = fmax(mx, fmax(fmax(cur.m[j], cur.i[j]), cur.d[j]));
@@ -150,7 +150,7 @@ __device__ void bwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
         cur.d[j] *= s;
     }
     if (lane == 0) cur.E = prev.E + e;
-    __syncthreads();
+    wave_sync();
 }
 
 template <int CAP>
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) sparse_backward_adaptive_kernel(const Spar
         const int nc = a.cand_n[gi];
         FVec<CAP> &c0 = cols[pos & 1];
         fv_clear(c0);
-        __syncthreads();
+        wave_sync();
         const uint32_t *cn = a.cand_node + (size_t)gi * PHMM_MAX_ACTIVE_NODES;
         const double *ct = a.cand_tot + (size_t)gi * PHMM_MAX_ACTIVE_NODES;
         for (int j = lane; j < nc; j += 64) {
@@ -187,13 +187,13 @@ __global__ void __launch_bounds__(64) sparse_backward_adaptive_kernel(const Spar
             c0.id[rank] = id;
             c0.m[rank] = c0.i[rank] = c0.d[rank] = 0.0;
         }
-        __syncthreads();
+        wave_sync();
         for (int j = lane; j < nc; j += 64) {
             const uint32_t cell = fv_cell(c0, c0.id[j]);
             c0.hslot[cell] = (uint16_t)j;
         }
         if (lane == 0) c0.n = nc;
-        __syncthreads();
+        wave_sync();
     }
     PrevRef<CAP> pr{};
     {
@@ -301,9 +301,9 @@ __global__ void __launch_bounds__(64) run_sparse_combine(const CombineArgs a) {
         if (!fdense && !bdense) {
             RecView F, B;
             if (!rec_view(a.fpool, p0 + (uint64_t)(j - 1), F) || !rec_view(a.bpool, p0 + (uint64_t)j, B)) continue;
-            __syncthreads();
+            wave_sync();
             for (int q = lane; q < B.n; q += 64) bid[q] = B.ids[q];
-            __syncthreads();
+            wave_sync();
             const double w = exp((double)(F.E + B.E) * SP_LN2 - logP);
             for (int q = lane; q < F.n; q += 64) {
                 const uint32_t id = F.ids[q];

@@ -130,6 +130,15 @@ __device__ __forceinline__ int wave_iscan(int v) {
 }
 __device__ __forceinline__ int wave_isum(int v) { return __builtin_amdgcn_readlane(wave_iscan(v), 63); }
 
+// Ordering point between the LDS accesses of the ONE wave of a 64-thread block (all frontier kernels).  The LDS
+// executes a wave's instructions in issue order, so lanes see each other's earlier writes without a barrier;
+// the compiler must keep the order, that is all.  __syncthreads() adds s_waitcnt vmcnt(0) on top: every
+// outstanding global load / store of the wave would be waited for at each sync point of a read position.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ int sp_exp_of(double v) {  // v*2^-e in [0.5,1); 0 for v == 0
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     const int be = (int)((bits >> 52) & 0x7ff);
@@ -190,13 +199,13 @@ __device__ uint32_t fwd_list_step(const SparseModel &M, const Col<CAP> &prev, Co
         cur.n = n;
         cur.na = n;
     }
-    __syncthreads();
+    wave_sync();
     for (int j = threadIdx.x; j < n; j += 64) {
         const uint32_t k = list[j];
         cur.id[j] = k;
         if (!hash_insert(cur, k, j)) err |= SP_ERR_DUPLICATE;
     }
-    __syncthreads();
+    wave_sync();
     // InsBegin of the previous column in the previous column's scale (fib, forward.rs:541-545)
     const double ibs = first ? 0.0 : exp(M.logib[pos - 1] - (double)prev.E * SP_LN2);
     const double c_begin = first ? lp.p_MM : lp.p_IM * ibs;  // p_MM*mb' + p_IM*ib'
@@ -238,7 +247,7 @@ __device__ uint32_t fwd_list_step(const SparseModel &M, const Col<CAP> &prev, Co
         cur.i[j] = inew;
         dA[j] = lp.p_MD * mnew + lp.p_ID * inew;  // g
     }
-    __syncthreads();
+    wave_sync();
     // fd0 (forward.rs:480-501) then n_max_gaps x fdt (510-524), restricted to the list
     double *src = dA, *dst = dB;
     for (int t = 0; t <= lp.n_max_gaps; t++) {
@@ -258,13 +267,13 @@ __device__ uint32_t fwd_list_step(const SparseModel &M, const Col<CAP> &prev, Co
             }
             dst[j] = s;
         }
-        __syncthreads();
+        wave_sync();
         double *tmp = src;
         src = dst;
         dst = tmp;
     }
     col_rescale(cur, first ? 0 : prev.E, ib_cur);
-    __syncthreads();
+    wave_sync();
     return err;
 }
 
@@ -292,13 +301,13 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
         cur.n = n;
         cur.na = n;
     }
-    __syncthreads();
+    wave_sync();
     for (int j = threadIdx.x; j < n; j += 64) {
         const uint32_t k = list[j];
         cur.id[j] = k;
         hash_insert(cur, k, j);
     }
-    __syncthreads();
+    wave_sync();
     const double pend = lp.p_end;
     // bd0 (backward.rs:354-377); keep A1 = sum_w t e_w m'[w] and q0 = p_r i'[v] for bm/bi
     for (int j = threadIdx.x; j < n; j += 64) {
@@ -342,7 +351,7 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
         cur.d[j] = d0;
         dA[j] = d0;
     }
-    __syncthreads();
+    wave_sync();
     // bdt (backward.rs:387-404), restricted to the list
     double *src = dA, *dst = dB;
     for (int t = 1; t <= lp.n_max_gaps; t++) {
@@ -367,7 +376,7 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
             dst[j] = s;
             cur.d[j] += s;
         }
-        __syncthreads();
+        wave_sync();
         double *tmp = src;
         src = dst;
         dst = tmp;
@@ -392,15 +401,15 @@ __device__ void bwd_list_step(const SparseModel &M, const Col<CAP> &prev, bool p
         }
         dA[j] = td;
     }
-    __syncthreads();
+    wave_sync();
     for (int j = threadIdx.x; j < n; j += 64) {
         const double a1 = cur.m[j], q0 = cur.i[j], td = dA[j];
         cur.m[j] = lp.p_MM * a1 + lp.p_MD * td + lp.p_MI * q0;
         cur.i[j] = lp.p_IM * a1 + lp.p_ID * td + lp.p_II * q0;
     }
-    __syncthreads();
+    wave_sync();
     col_rescale(cur, prev_is_init ? 0 : prev.E, 0.0);
-    __syncthreads();
+    wave_sync();
 }
 
 // fe (forward.rs:554-558): ln(p_end * sum over the active list of m+i+d) + E ln2

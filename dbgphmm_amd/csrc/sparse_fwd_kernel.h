@@ -46,7 +46,7 @@ template <int CAP> __device__ bool load_record_fvec(const RecPool &p, uint64_t p
     const int n = hw[0], na = hw[1], E = hw[2];
     if (n > CAP) return false;
     fv_clear(f);
-    __syncthreads();
+    wave_sync();
     const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
     const uint32_t *ids = (const uint32_t *)(rec + 16);
     const double *m = (const double *)(rec + 16 + idb), *i = m + na, *d = i + na;
@@ -64,7 +64,7 @@ template <int CAP> __device__ bool load_record_fvec(const RecPool &p, uint64_t p
         f.na = na;
         f.E = E;
     }
-    __syncthreads();
+    wave_sync();
     return true;
 }
 
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64) sparse_forward_kernel(const SparseFwdArgs 
     const uint64_t p0 = a.lane_pos0[gi];
     constexpr bool SMALL = CAP < PHMM_MAX_ACTIVE_NODES;
     if (lane == 0) sc.dropped = 0;
-    __syncthreads();
+    wave_sync();
     uint32_t err = 0;
     int pos;        // next position to compute
     int end = len;  // first position this launch does not compute
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64) sparse_forward_kernel(const SparseFwdArgs 
         const int nc = a.cand_n[gi];
         FVec<CAP> &c0 = cols[s0 & 1];
         fv_clear(c0);
-        __syncthreads();
+        wave_sync();
         if (nc > CAP) {
             err |= SP_ERR_CAPACITY;
             done_to = s0;
@@ -112,13 +112,13 @@ __global__ void __launch_bounds__(64) sparse_forward_kernel(const SparseFwdArgs 
                 c0.id[rank] = id;
                 c0.m[rank] = c0.i[rank] = c0.d[rank] = 0.0;
             }
-            __syncthreads();
+            wave_sync();
             for (int j = lane; j < nc; j += 64) {
                 const uint32_t cell = fv_cell(c0, c0.id[j]);
                 c0.hslot[cell] = (uint16_t)j;
             }
             if (lane == 0) c0.n = nc;
-            __syncthreads();
+            wave_sync();
             PrevRef<CAP> pr{};
             pr.vec = nullptr;
             pr.gm = a.d.Fm + ((size_t)g * a.d.Lc + (s0 - 1)) * NW;
