@@ -269,6 +269,20 @@ void model_upload(phmm_model *m) {
     }
     d.fadj.upload(fadj.data(), sizeof(FwdAdj) * N);
     d.badj.upload(badj.data(), sizeof(BwdAdj) * N);
+    std::vector<ParRec> prec(N);
+    for (uint32_t v = 0; v < N; v++) {
+        ParRec r{};
+        const uint32_t np = m->par_off[v + 1] - m->par_off[v];
+        r.over = np > (uint32_t)ADJ_DEG ? 1 : 0;
+        r.npar = (uint8_t)std::min<uint32_t>(np, ADJ_DEG);
+        r.emis = m->emission[v];
+        for (uint32_t q = 0; q < (uint32_t)ADJ_DEG; q++) {
+            r.par[q] = q < r.npar ? m->par_node[m->par_off[v] + q] : 0xffffffffu;
+            r.pedge[q] = q < r.npar ? m->par_edge[m->par_off[v] + q] : 0u;
+        }
+        prec[v] = r;
+    }
+    d.prec.upload(prec.data(), sizeof(ParRec) * N);
     d.max_degree = 0;
     for (uint32_t v = 0; v < N; v++)
         d.max_degree = std::max(d.max_degree, std::max(m->par_off[v + 1] - m->par_off[v], m->chi_off[v + 1] - m->chi_off[v]));

@@ -148,7 +148,15 @@ struct alignas(16) BwdAdj {   // backward: sums over children
     uint8_t emis, nchi, over;
     uint32_t pad;
 };
-static_assert(sizeof(FwdAdj) == 96 && sizeof(BwdAdj) == 80, "adjacency record layout");
+// Topology-only record of the hinted forward (candidate batches bring their own init / trans): parents with the
+// ids of their edges, so that trans[candidate][edge] is one dependent load behind the record.
+struct alignas(16) ParRec {
+    uint32_t par[ADJ_DEG];
+    uint32_t pedge[ADJ_DEG];
+    uint8_t npar, emis, over, pad;
+    uint32_t pad2;
+};
+static_assert(sizeof(FwdAdj) == 96 && sizeof(BwdAdj) == 80 && sizeof(ParRec) == 48, "adjacency record layout");
 
 struct ModelDev {
     uint32_t N = 0, E = 0;
@@ -166,6 +174,7 @@ struct ModelDev {
     DevBuf par_edge, chi_edge;        // u32[E] edge ids (candidate batches index trans by edge)
     DevBuf trans_lin;                 // f64[E] by edge id
     DevBuf fadj, badj;                // FwdAdj[N], BwdAdj[N]
+    DevBuf prec;                      // ParRec[N]
     DevBuf logib;                     // f64[logib_len] forward InsBegin chain (log)
     size_t logib_len = 0;
     uint32_t max_degree = 0;

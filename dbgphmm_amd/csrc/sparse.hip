@@ -72,6 +72,210 @@ __global__ void __launch_bounds__(64) hinted_score_kernel(const HintedArgs a) {
     }
 }
 
+// The same recursion for the <= 64-node class on graphs of degree <= 5 (every DBG), ONE LANE PER LIST ENTRY:
+//   * a column lives in registers (m, i, d of the entry on its lane); the LDS only holds two small hashes
+//     node -> lane (previous and current list).  Parents' values come by ds_bpermute: the previous column enters
+//     through G = p_MM m + p_IM i + p_DM d (one shuffle per parent), the Del levels through the level value;
+//   * software-pipelined over the positions: list offsets, node ids, their parent records (ParRec) and init
+//     values and the base are requested one or two positions ahead, trans[edge] as soon as the record is there.
+// The generic kernel (fwd_list_step) keeps the column in LDS and walks offsets -> ids -> CSR -> edges -> trans:
+// ~25 dependent LDS and 5 dependent global round trips per position.  Same sums in the same order.
+static constexpr int HL_HASH = 128;
+struct HintedLeanShared {
+    uint2 ent[2][HL_HASH];  // {node, lane} of the list of position parity
+};
+__device__ __forceinline__ uint32_t hl_hash(uint32_t id) { return (id * 2654435761u) >> 25; }
+__device__ __forceinline__ int hl_find(const uint2 *ent, uint32_t id) {
+    uint32_t h = hl_hash(id);
+    for (;;) {
+        const uint2 e = ent[h];
+        if (e.x == id) return (int)e.y;
+        if (e.x == 0xffffffffu) return -1;
+        h = (h + 1) & (HL_HASH - 1);
+    }
+}
+__device__ __forceinline__ double hl_shfl(double v, int src) { return __shfl(v, src < 0 ? 0 : src); }
+
+__global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
+    constexpr int CAP = 64;
+    __shared__ HintedLeanShared sh;
+    const int lane = threadIdx.x;
+    const uint32_t rd = a.read_ids[blockIdx.x];
+    const uint32_t cand = blockIdx.y;
+    const double *init = a.init_c + (size_t)cand * a.M.N;
+    const double *trans = a.trans_c + (size_t)cand * a.E;
+    const ParRec *prec = a.M.prec;
+    const LinParams &lp = a.M.lp;
+    const uint64_t b0 = a.read_off[rd];
+    const int len = (int)(a.read_off[rd + 1] - b0);
+    const uint64_t *po = a.map_pos_off + b0;
+    uint32_t err = 0;
+    // pipeline: (o, n, id, x) of the current and the next position, records and weights of the current one
+    uint64_t o_cur = po[0], o_nx = po[1], o_n2 = po[len >= 2 ? 2 : 1];
+    int n_cur = (int)(o_nx - o_cur), n_nx = len >= 2 ? (int)(o_n2 - o_nx) : 0;
+    // (inactive lanes read node 0: every load below is unconditional)
+    uint32_t id_cur = (lane < n_cur && n_cur <= CAP) ? a.map_nodes[o_cur + lane] : 0u;
+    uint32_t id_nx = (lane < n_nx && n_nx <= CAP) ? a.map_nodes[o_nx + lane] : 0u;
+    ParRec rc_cur = prec[id_cur];
+    double in_cur = init[id_cur];
+    double w_cur[ADJ_DEG];
+#pragma unroll
+    for (int q = 0; q < ADJ_DEG; q++) w_cur[q] = q < (int)rc_cur.npar ? trans[rc_cur.pedge[q]] : 0.0;
+    uint8_t x_cur = a.bases[b0], x_nx = len >= 2 ? a.bases[b0 + 1] : (uint8_t)0;
+    double lib_cur = 0.0, lib_nx = a.M.logib[0];  // logib[pos - 1] of the position
+    // previous column on the lanes of ITS list order
+    double pm = 0.0, pi = 0.0, pd = 0.0, m = 0.0, ii = 0.0, d = 0.0;
+    int Eprev = 0, n_prev = 0;
+    for (int pos = 0; pos < len; pos++) {
+        if (n_cur > CAP) {
+            err |= SP_ERR_CAPACITY;
+            break;
+        }
+        // ---- requests for the positions ahead
+        const ParRec rc_nx = prec[id_nx];
+        const double in_nx = init[id_nx];
+        const uint64_t o_n3 = po[pos + 3 <= len ? pos + 3 : len];
+        const int n_n2 = pos + 2 < len ? (int)(o_n3 - o_n2) : 0;
+        const uint32_t id_n2 = (lane < n_n2 && n_n2 <= CAP) ? a.map_nodes[o_n2 + lane] : 0u;
+        const uint8_t x_n2 = pos + 2 < len ? a.bases[b0 + pos + 2] : (uint8_t)0;
+        const double lib_n2 = a.M.logib[pos + 1];
+        // ---- hash of this position's list
+        const bool first = pos == 0;
+        const int n = n_cur;
+        const bool has = lane < n;
+        uint2 *hc = sh.ent[pos & 1];
+        const uint2 *hp = sh.ent[(pos + 1) & 1];
+        for (int h = lane; h < HL_HASH; h += 64) hc[h].x = 0xffffffffu;
+        wave_sync();
+        if (has) {
+            uint32_t h = hl_hash(id_cur);
+            for (;;) {
+                const uint32_t old = atomicCAS(&hc[h].x, 0xffffffffu, id_cur);
+                if (old == 0xffffffffu) break;
+                if (old == id_cur) {
+                    err |= SP_ERR_DUPLICATE;
+                    break;
+                }
+                h = (h + 1) & (HL_HASH - 1);
+            }
+            hc[h].y = (uint32_t)lane;
+        }
+        wave_sync();
+        // ---- fm, fi (forward.rs:337-388), fib (541-545)
+        const double ibs = first ? 0.0 : exp(lib_cur - (double)Eprev * SP_LN2);
+        const double c_begin = first ? lp.p_MM : lp.p_IM * ibs;
+        const double ib_cur = first ? lp.p_random * lp.p_MI : lp.p_random * lp.p_II * ibs;
+        const double c_del = lp.p_ID * ib_cur;
+        const bool hadp = lane < n_prev;
+        const double G = hadp ? lp.p_MM * pm + lp.p_IM * pi + lp.p_DM * pd : 0.0;
+        const double H = hadp ? lp.p_MI * pm + lp.p_II * pi + lp.p_DI * pd : 0.0;
+        int ps[ADJ_DEG], cs[ADJ_DEG];
+        uint32_t anyq = 0;  // wave-uniform: some lane has a q-th parent (on a DBG mostly q = 0 only)
+#pragma unroll
+        for (int q = 0; q < ADJ_DEG; q++) {
+            const bool use = has && q < (int)rc_cur.npar && w_cur[q] != 0.0;
+            ps[q] = cs[q] = -1;
+            if (__ballot(use) != 0ull) {
+                anyq |= 1u << q;
+                ps[q] = (use && !first) ? hl_find(hp, rc_cur.par[q]) : -1;
+                cs[q] = use ? hl_find(hc, rc_cur.par[q]) : -1;
+            }
+        }
+        const int os = (has && !first) ? hl_find(hp, id_cur) : -1;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < ADJ_DEG; q++) {
+            if (!(anyq & (1u << q))) continue;
+            const double v = hl_shfl(G, ps[q]);
+            if (ps[q] >= 0) acc += w_cur[q] * v;
+        }
+        const double hv = hl_shfl(H, os);
+        m = ii = d = 0.0;
+        if (has) {
+            const double pe = rc_cur.emis == x_cur ? lp.p_match : lp.p_mismatch;
+            m = pe * (acc + in_cur * c_begin);
+            ii = os >= 0 ? lp.p_random * hv : 0.0;
+        }
+        // ---- fd0 + n_max_gaps x fdt restricted to the list (forward.rs:423-524)
+        double lv = lp.p_MD * m + lp.p_ID * ii;
+        for (int t = 0; t <= lp.n_max_gaps; t++) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < ADJ_DEG; q++) {
+                if (!(anyq & (1u << q))) continue;
+                const double v = hl_shfl(lv, cs[q]);
+                if (cs[q] >= 0) sacc += w_cur[q] * v;
+            }
+            if (t == 0) sacc += in_cur * c_del;
+            else sacc *= lp.p_DD;
+            sacc = has ? sacc : 0.0;
+            d += sacc;
+            lv = sacc;
+        }
+        // ---- rescale so that the column maximum is in [0.5, 1)
+        const double mx = wave_max(fmax(has ? fmax(fmax(m, ii), d) : 0.0, ib_cur));
+        const int e = sp_exp_of(mx);
+        const double sc = sp_pow2(-e);
+        m *= sc;
+        ii *= sc;
+        d *= sc;
+        const int Ecur = (first ? 0 : Eprev) + e;
+        if (a.pool.base && cand == 0) {
+            // forward record of the position (every entry carries m, i and d)
+            const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
+            const uint64_t bytes = 16 + idb + (uint64_t)(3 * n) * 8;
+            const uint64_t o = pool_alloc(a.pool, bytes);
+            if (o + bytes > a.pool.cap) err |= SP_ERR_POOL;
+            else {
+                uint8_t *rec = a.pool.base + o;
+                if (lane == 0) {
+                    ((uint32_t *)rec)[0] = (uint32_t)n;
+                    ((uint32_t *)rec)[1] = (uint32_t)n;
+                    ((int *)rec)[2] = Ecur;
+                    ((uint32_t *)rec)[3] = 0;
+                    a.pool.off[b0 + pos] = o + 8;
+                }
+                if (has) {
+                    ((uint32_t *)(rec + 16))[lane] = id_cur;
+                    double *om = (double *)(rec + 16 + idb);
+                    om[lane] = m;
+                    om[n + lane] = ii;
+                    om[2 * n + lane] = d;
+                }
+            }
+        }
+        // ---- the column becomes the previous one; weights of the next position (its record has arrived)
+        pm = m;
+        pi = ii;
+        pd = d;
+        Eprev = Ecur;
+        n_prev = n;
+#pragma unroll
+        for (int q = 0; q < ADJ_DEG; q++) w_cur[q] = q < (int)rc_nx.npar ? trans[rc_nx.pedge[q]] : 0.0;
+        o_cur = o_nx;
+        o_nx = o_n2;
+        o_n2 = o_n3;
+        n_cur = n_nx;
+        n_nx = n_n2;
+        id_cur = id_nx;
+        id_nx = id_n2;
+        rc_cur = rc_nx;
+        in_cur = in_nx;
+        x_cur = x_nx;
+        x_nx = x_n2;
+        lib_cur = lib_nx;
+        lib_nx = lib_n2;
+    }
+    for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
+    // fe (forward.rs:554-558) of the last column
+    const double stot = wave_sum(lane < n_prev ? pm + pi + pd : 0.0);
+    const double lpv = err ? NAN : log(lp.p_end * stot) + (double)Eprev * SP_LN2;
+    if (lane == 0) {
+        a.out_logp[(size_t)cand * a.R + rd] = lpv;
+        a.err[(size_t)cand * a.R + rd] = err;
+    }
+}
+
 __global__ void __launch_bounds__(256) exp_kernel(const double *in, double *out, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
@@ -110,6 +314,7 @@ SparseModel sparse_model(const phmm_model *m) {
     s.chi_node = d.chi_node.as<uint32_t>();
     s.chi_edge = d.chi_edge.as<uint32_t>();
     s.trans = d.trans_lin.as<double>();
+    s.prec = d.prec.as<ParRec>();
     s.lp = m->lin;
     s.logib = d.logib.as<double>();
     return s;
@@ -272,7 +477,9 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
     for (int c = 0; c < 3; c++) {
         if (cls[c].empty()) continue;
         HIP_CHECK(hipMemcpyAsync(d_ids.p, cls[c].data(), cls[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        if (c == 0) launch_hinted<64, 2>(a, (uint32_t)cls[c].size(), n_cand);
+        if (c == 0 && m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr) {
+            hipLaunchKernelGGL(hinted_lean_kernel, dim3((unsigned)cls[c].size(), n_cand), dim3(64), 0, s, a);
+        } else if (c == 0) launch_hinted<64, 2>(a, (uint32_t)cls[c].size(), n_cand);
         else if (c == 1) launch_hinted<128, 4>(a, (uint32_t)cls[c].size(), n_cand);
         else launch_hinted<400, 8>(a, (uint32_t)cls[c].size(), n_cand);
         HIP_CHECK(hipGetLastError());

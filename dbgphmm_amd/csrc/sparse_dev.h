@@ -161,6 +161,7 @@ struct SparseModel {
     const double *par_w, *chi_w;  // [E] linear trans prob aligned with par_node / chi_node (the model's own)
     const FwdAdj *fadj;           // [N] packed per-node records (the model's own init / trans)
     const BwdAdj *badj;
+    const ParRec *prec;           // [N] parents + edge ids (hinted forward)
     LinParams lp;
     const double *logib;  // forward InsBegin chain (log), [>= max read length]
 };

@@ -96,6 +96,7 @@ inline SparseModel sparse_model_of(const phmm_model *m) {
     s.trans = d.trans_lin.as<double>();
     s.fadj = d.fadj.as<FwdAdj>();
     s.badj = d.badj.as<BwdAdj>();
+    s.prec = d.prec.as<ParRec>();
     s.par_w = d.par_w.as<double>();
     s.chi_w = d.chi_w.as<double>();
     s.lp = m->lin;
