@@ -122,15 +122,28 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
 #pragma unroll
     for (int q = 0; q < ADJ_DEG; q++) w_cur[q] = q < (int)rc_cur.npar ? trans[rc_cur.pedge[q]] : 0.0;
     uint8_t x_cur = a.bases[b0], x_nx = len >= 2 ? a.bases[b0 + 1] : (uint8_t)0;
-    double lib_cur = 0.0, lib_nx = a.M.logib[0];  // logib[pos - 1] of the position
     // previous column on the lanes of ITS list order
-    double pm = 0.0, pi = 0.0, pd = 0.0, m = 0.0, ii = 0.0, d = 0.0;
+    double pm = 0.0, pi = 0.0, pd = 0.0, m = 0.0, ii = 0.0, d = 0.0, ibs = 0.0;
     int Eprev = 0, n_prev = 0;
+#ifdef PHMM_LEAN_PROF
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = 0;
+#define HPROF(k)                          \
+    {                                     \
+        const long long now_ = clock64(); \
+        pt[k] += now_ - pc0;              \
+        pc0 = now_;                       \
+    }
+#else
+#define HPROF(k)
+#endif
     for (int pos = 0; pos < len; pos++) {
         if (n_cur > CAP) {
             err |= SP_ERR_CAPACITY;
             break;
         }
+#ifdef PHMM_LEAN_PROF
+        pc0 = clock64();
+#endif
         // ---- requests for the positions ahead
         const ParRec rc_nx = prec[id_nx];
         const double in_nx = init[id_nx];
@@ -138,7 +151,7 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
         const int n_n2 = pos + 2 < len ? (int)(o_n3 - o_n2) : 0;
         const uint32_t id_n2 = (lane < n_n2 && n_n2 <= CAP) ? a.map_nodes[o_n2 + lane] : 0u;
         const uint8_t x_n2 = pos + 2 < len ? a.bases[b0 + pos + 2] : (uint8_t)0;
-        const double lib_n2 = a.M.logib[pos + 1];
+        HPROF(0)
         // ---- hash of this position's list
         const bool first = pos == 0;
         const int n = n_cur;
@@ -161,8 +174,10 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
             hc[h].y = (uint32_t)lane;
         }
         wave_sync();
+        HPROF(1)
         // ---- fm, fi (forward.rs:337-388), fib (541-545)
-        const double ibs = first ? 0.0 : exp(lib_cur - (double)Eprev * SP_LN2);
+        // (InsBegin of the previous column in that column's scale, fib forward.rs:541-545: carried along with the
+        // exact power-of-two rescales instead of exp(logib[pos-1] - E ln 2) per position)
         const double c_begin = first ? lp.p_MM : lp.p_IM * ibs;
         const double ib_cur = first ? lp.p_random * lp.p_MI : lp.p_random * lp.p_II * ibs;
         const double c_del = lp.p_ID * ib_cur;
@@ -182,6 +197,7 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
             }
         }
         const int os = (has && !first) ? hl_find(hp, id_cur) : -1;
+        HPROF(2)
         double acc = 0.0;
 #pragma unroll
         for (int q = 0; q < ADJ_DEG; q++) {
@@ -196,6 +212,7 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
             m = pe * (acc + in_cur * c_begin);
             ii = os >= 0 ? lp.p_random * hv : 0.0;
         }
+        HPROF(3)
         // ---- fd0 + n_max_gaps x fdt restricted to the list (forward.rs:423-524)
         double lv = lp.p_MD * m + lp.p_ID * ii;
         for (int t = 0; t <= lp.n_max_gaps; t++) {
@@ -212,6 +229,7 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
             d += sacc;
             lv = sacc;
         }
+        HPROF(4)
         // ---- rescale so that the column maximum is in [0.5, 1)
         const double mx = wave_max(fmax(has ? fmax(fmax(m, ii), d) : 0.0, ib_cur));
         const int e = sp_exp_of(mx);
@@ -220,6 +238,7 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
         ii *= sc;
         d *= sc;
         const int Ecur = (first ? 0 : Eprev) + e;
+        ibs = ib_cur * sc;
         if (a.pool.base && cand == 0) {
             // forward record of the position (every entry carries m, i and d)
             const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
@@ -244,6 +263,7 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
                 }
             }
         }
+        HPROF(5)
         // ---- the column becomes the previous one; weights of the next position (its record has arrived)
         pm = m;
         pi = ii;
@@ -263,9 +283,13 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
         in_cur = in_nx;
         x_cur = x_nx;
         x_nx = x_n2;
-        lib_cur = lib_nx;
-        lib_nx = lib_n2;
+        HPROF(6)
     }
+#ifdef PHMM_LEAN_PROF
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && len > 0)
+        printf("hinted_lean prof: len %d | requests %lld hash %lld exp+lookups %lld fm %lld del %lld rescale+store %lld rotate+weights %lld (cycles/step)\n",
+               len, pt[0] / len, pt[1] / len, pt[2] / len, pt[3] / len, pt[4] / len, pt[5] / len, pt[6] / len);
+#endif
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
     // fe (forward.rs:554-558) of the last column
     const double stot = wave_sum(lane < n_prev ? pm + pi + pd : 0.0);
