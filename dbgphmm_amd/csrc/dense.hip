@@ -762,6 +762,8 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
     if (threadIdx.x < W && live && lb < a.nblk)
         atomicMax(&a.cmaxB[((size_t)g * a.Lc + pos) * W + r], (unsigned long long)__double_as_longlong(bmx));
     if (a.want_map) {
+        // the run's own maximum: post_collect reads one value per run and only revisits the runs above the threshold
+        if (a.Prun) a.Prun[((size_t)g * a.nblk8 + lb) * BLOCK + threadIdx.x] = pmx;
         const double p1 = block_reduce_rows<W>(pmx, OpMax(), lds);
         if (threadIdx.x < W && live && lb < a.nblk)
             atomicMax(&a.pmax[((size_t)g * (a.Lc + 1) + pos) * W + r], (unsigned long long)__double_as_longlong(p1));

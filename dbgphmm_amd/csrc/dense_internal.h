@@ -56,6 +56,7 @@ struct DenseArgs {
     const int *bstart;             // [ng][W] last dense backward column of each read (null: len-1)
     int want_map;                  // keep the per-node emit probs of the column in Pa/Pb
     double *Pa, *Pb;               // [ng][N][W] emit probs of merged index pos / len
+    double *Prun;                  // [ng][nblk8][BLOCK] per thread: maximum of Pa over its run of npt nodes (null: off)
     unsigned long long *pmax;      // [ng][Lc+1][W] their maxima, by merged index
     // dense warm-up of the adaptive sparse forward (sparse_dyn.hip): launch pos also counts the nodes of
     // column pos-1 inside the score ratio (top_nodes_by_score_ratio, table.rs:134-149) -- see WarmFuse

@@ -283,8 +283,34 @@ __global__ void __launch_bounds__(BLOCK) post_collect(const DenseMapArgs ma, con
     const bool doB = live && pos == len - 1 && !sparse_tail;
     if (lb >= a.nblk) return;
     const size_t NW = (size_t)a.N * W;
+    if (a.Prun && doA) {
+        // bwd_step left the maximum of each thread's run (npt consecutive nodes): one read per run, and only
+        // the runs above the threshold -- a handful per read -- go back to the emit-prob plane
+        const double thr = __longlong_as_double((long long)a.pmax[((size_t)g * (a.Lc + 1) + pos) * W + r]) * ma.ratio_lin;
+        const double rm = a.Prun[((size_t)g * a.nblk8 + lb) * BLOCK + threadIdx.x];
+        if (rm > 0.0 && rm > thr) {
+            const double *P = a.Pa + (size_t)g * NW;
+            const int k0 = lb * (a.npt * ROWS) + row * a.npt;
+            uint32_t *cn = ma.candA_node + (size_t)gi * KMAX;
+            double *cv = ma.candA_val + (size_t)gi * KMAX;
+            int local = 0;
+            for (int j = 0; j < a.npt && k0 + j < a.N; j++) {
+                const double t = P[(size_t)(k0 + j) * W + r];
+                local += (t > 0.0 && t > thr) ? 1 : 0;
+            }
+            int slot = atomicAdd(&ma.cntA[gi], local);
+            for (int j = 0; j < a.npt && k0 + j < a.N && slot < KMAX; j++) {
+                const double t = P[(size_t)(k0 + j) * W + r];
+                if (t > 0.0 && t > thr) {
+                    cn[slot] = (uint32_t)(k0 + j);
+                    cv[slot] = t;
+                    slot++;
+                }
+            }
+        }
+    }
     const int kbase = lb * (a.npt * ROWS) + row;
-    for (int which = 0; which < 2; which++) {
+    for (int which = (a.Prun ? 1 : 0); which < 2; which++) {
         if (!(which == 0 ? doA : doB)) continue;
         const double *P = (which == 0 ? a.Pa : a.Pb) + (size_t)g * NW;
         const int mi = which == 0 ? pos : len;
@@ -511,7 +537,9 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
                  o_hand = carve(sizeof(BHandoff) * (size_t)lanes);
     ctl.reserve(cb);
     char *cp = (char *)ctl.p;
-    pbuf.reserve(3 * (size_t)mc.ngc * NW * sizeof(double));  // Pa (two buffers, by position parity) and Pb
+    // Pa (two buffers, by position parity), Pb and the per-run maxima of Pa
+    const size_t prun_n = (size_t)mc.ngc * mc.a.nblk8 * BLOCK;
+    pbuf.reserve((3 * (size_t)mc.ngc * NW + prun_n) * sizeof(double));
     unsigned long long top_before = 0;
     HIP_CHECK(hipMemcpyAsync(&top_before, sink->mp.top, sizeof(top_before), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -532,6 +560,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         a.bstart = (const int *)(cp + o_bs);
         a.Pa = pbuf.as<double>();
         a.Pb = pbuf.as<double>() + 2 * (size_t)mc.ngc * NW;
+        a.Prun = std::getenv("PHMM_NO_RUNMAX") ? nullptr : pbuf.as<double>() + 3 * (size_t)mc.ngc * NW;
         // backward scratch of the chunk must start clean (a previous attempt may have used it)
         HIP_CHECK(hipMemsetAsync(a.cmaxB, 0, sizeof(unsigned long long) * (size_t)a.ng * a.Lc * W, s));
         HIP_CHECK(hipMemsetAsync(a.pmax, 0, sizeof(unsigned long long) * (size_t)a.ng * (a.Lc + 1) * W, s));
