@@ -663,7 +663,12 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         // the column where more than 400 nodes are inside the ratio) runs on a side stream under the next
         // columns' bwd_step; the emit-prob plane is double-buffered by position parity for that.
         const int wi = workset_index();
-        if (!m->cstream[wi]) HIP_CHECK(hipStreamCreateWithFlags(&m->cstream[wi], hipStreamNonBlocking));
+        if (!m->cstream[wi]) {
+            // lowest priority: the list kernels fill the gaps, the HBM-bound bwd_step keeps the machine
+            int least = 0, greatest = 0;
+            HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_CHECK(hipStreamCreateWithPriority(&m->cstream[wi], hipStreamNonBlocking, least));
+        }
         for (auto &e : m->cevent[wi])
             if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         hipStream_t s2 = m->cstream[wi];
