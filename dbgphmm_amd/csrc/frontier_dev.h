@@ -83,9 +83,12 @@ template <int CAP> __device__ __forceinline__ void sort_desc(const double *tot, 
     for (int j = threadIdx.x; j < n; j += 64) {
         const double v = tot[j];
         int rank = 0;
-        for (int q = 0; q < n; q++) {
-            const double u = tot[q];
-            rank += (u > v) || (u == v && q < j);
+        for (int q0 = 0; q0 < n; q0 += 8) {  // (eight LDS reads in flight instead of one at a time)
+            double u[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) u[k] = tot[q0 + k < n ? q0 + k : n - 1];
+#pragma unroll
+            for (int k = 0; k < 8; k++) rank += (q0 + k < n) && ((u[k] > v) || (u[k] == v && q0 + k < j));
         }
         order[rank] = (uint16_t)j;
     }

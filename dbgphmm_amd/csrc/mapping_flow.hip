@@ -62,26 +62,41 @@ template <int CAP> __device__ bool load_record(const RecPool &p, uint64_t pos_in
 template <int CAP>
 __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32_t *ids, const double *val, int n,
                              double ratio_lin, bool by_node, uint16_t *order, int topk = 0) {
+    // Only the entries that stay need a rank: with the ratio rule they are the largest ones, so their rank among
+    // all entries is their rank among themselves (a column next to the dense/sparse switch has up to 400
+    // entries of which a handful stay).
+    double thr = -1.0;  // topk: every entry is ranked
+    if (topk <= 0) {
+        double mx = 0.0;
+        for (int j = threadIdx.x; j < n; j += 64) mx = fmax(mx, val[j]);
+        thr = wave_max(mx) * ratio_lin;
+    }
+    int c = 0;
     for (int j = threadIdx.x; j < n; j += 64) {
         const double v = val[j];
+        if (topk <= 0 && !(v > 0.0 && v > thr)) continue;
         const uint32_t id = ids[j];
         int rank = 0;
-        for (int q = 0; q < n; q++) {
-            const double u = val[q];
-            rank += (u > v) || (u == v && (by_node ? ids[q] < id : q < j));
+        for (int q0 = 0; q0 < n; q0 += 8) {  // (eight LDS reads in flight)
+            double u[8];
+            uint32_t ui[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int q = q0 + k < n ? q0 + k : n - 1;
+                u[k] = val[q];
+                ui[k] = by_node ? ids[q] : (uint32_t)q;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                rank += (q0 + k < n) && ((u[k] > v) || (u[k] == v && (by_node ? ui[k] < id : (int)ui[k] < j)));
         }
         order[rank] = (uint16_t)j;
+        c++;
     }
     __syncthreads();
     int keep = 0;
-    if (topk > 0) {
-        keep = topk < n ? topk : n;  // to_mapping(n_active_nodes): the k best whatever their value (hint.rs:124-131)
-    } else if (n > 0) {
-        const double p0 = val[order[0]];
-        int c = 0;
-        for (int j = threadIdx.x; j < n; j += 64) c += (val[j] > 0.0 && val[j] > p0 * ratio_lin) ? 1 : 0;
-        keep = wave_isum(c);
-    }
+    if (topk > 0) keep = topk < n ? topk : n;  // to_mapping(n_active_nodes): the k best whatever their value (hint.rs:124-131)
+    else keep = wave_isum(c);
     const uint64_t idb = (uint64_t)((keep + 1) & ~1) * 4;
     const uint64_t bytes = 8 + idb + (uint64_t)keep * 8;
     const uint64_t o = pool_alloc(mp, bytes);
