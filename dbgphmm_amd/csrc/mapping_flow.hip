@@ -61,7 +61,7 @@ template <int CAP> __device__ bool load_record(const RecPool &p, uint64_t pos_in
 // write [n][pad] ids logp.  Returns false if the pool is full.
 template <int CAP>
 __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32_t *ids, const double *val, int n,
-                             double ratio_lin, bool by_node, uint16_t *order, int topk = 0) {
+                             double ratio_lin, bool by_node, uint16_t *order, int topk = 0, long long prealloc = -1) {
     // Only the entries that stay need a rank: with the ratio rule they are the largest ones, so their rank among
     // all entries is their rank among themselves (a column next to the dense/sparse switch has up to 400
     // entries of which a handful stay).
@@ -99,7 +99,8 @@ __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32
     else keep = wave_isum(c);
     const uint64_t idb = (uint64_t)((keep + 1) & ~1) * 4;
     const uint64_t bytes = 8 + idb + (uint64_t)keep * 8;
-    const uint64_t o = pool_alloc(mp, bytes);
+    // (prealloc: the caller reserved room for this record -- emit_offsets -- instead of one atomic per record)
+    const uint64_t o = prealloc >= 0 ? (uint64_t)prealloc : pool_alloc(mp, bytes);
     if (o + bytes > mp.cap) return false;
     uint8_t *rec = mp.base + o;
     if (threadIdx.x == 0) {
@@ -280,6 +281,7 @@ struct DenseMapArgs {
     double ratio_lin;
     int topk;
     uint32_t *err;
+    unsigned long long *eoff;  // [2][lanes] record offsets of the column being emitted (emit_offsets)
 };
 
 template <int W>
@@ -427,6 +429,57 @@ __device__ int block_top_from_column(const double *col, int stride, int N, doubl
     return s_n < KMAX ? s_n : KMAX;
 }
 
+// Room for the records of one column in ONE allocation: every (lane, which) that emit_dense_map will write gets
+// an offset from an upper bound of its record size (the candidate count; the ratio rule can only shorten the
+// list).  One atomic per column instead of one per record: 4 000 blocks adding to the same word cost 2.8 ms a
+// column, and the columns in which every read is still dense are the last ones, with nothing left to hide behind.
+__global__ void __launch_bounds__(1024) emit_offsets(const DenseMapArgs ma, const int pos, const int lanes) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long s_base;
+    const DenseArgs &a = ma.d;
+    const int tid = threadIdx.x;
+    const int items = 2 * lanes;
+    const int per = (items + 1023) / 1024;
+    auto bytes_of = [&](int it) -> unsigned long long {
+        if (it >= items) return 0ull;
+        const int which = it / lanes, gi = it % lanes;
+        const int len = a.len[gi];
+        if (len == 0) return 0ull;
+        const int braw = a.bstart[gi];
+        const bool sparse_tail = (braw & (1 << 30)) != 0;
+        const int bstart = braw & ~(1 << 30);
+        const bool live = pos < len && pos <= bstart;
+        const bool mine = which == 0 ? (live && pos >= 1) : (live && pos == len - 1 && !sparse_tail);
+        if (!mine) return 0ull;
+        const int c = (which == 0 ? ma.cntA : ma.cntB)[gi];
+        int k = c < KMAX ? c : KMAX;
+        if (ma.topk > 0) {
+            const int want = ma.topk < a.N ? ma.topk : a.N;
+            k = k > want ? k : want;
+        }
+        return 8ull + (unsigned long long)((k + 1) & ~1) * 4ull + (unsigned long long)k * 8ull;
+    };
+    unsigned long long loc = 0ull;
+    for (int q = 0; q < per; q++) loc += bytes_of(tid * per + q);
+    part[tid] = loc;
+    __syncthreads();
+    // exclusive scan of the 1024 partial sums (Hillis-Steele)
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned long long v = tid >= off ? part[tid - off] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    if (tid == 1023) s_base = atomicAdd(ma.mpool.top, part[1023]);
+    __syncthreads();
+    unsigned long long o = s_base + part[tid] - loc;
+    for (int q = 0; q < per; q++) {
+        const int it = tid * per + q;
+        if (it < items) ma.eoff[it] = o;
+        o += bytes_of(it);
+    }
+}
+
 // one wave per (lane, which): sort the collected nodes and write the mapping record
 __global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, const int pos) {
     __shared__ uint32_t ids[KMAX];
@@ -481,7 +534,8 @@ __global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, c
     __syncthreads();
     if (threadIdx.x >= 64) return;  // the sort + record write is a single-wave job
     const uint64_t pidx = ma.lane_pos0[gi] + (uint64_t)(mi - 1);
-    if (!emit_mapping<KMAX>(ma.mpool, pidx, ids, val, n, ma.ratio_lin, true, order, ma.topk)) {
+    if (!emit_mapping<KMAX>(ma.mpool, pidx, ids, val, n, ma.ratio_lin, true, order, ma.topk,
+                            (long long)ma.eoff[(size_t)which * gridDim.x + gi])) {
         if (threadIdx.x == 0) atomicOr(&ma.err[gi], SP_ERR_POOL);
     }
     if (threadIdx.x == 0) cnt[gi] = 0;
@@ -549,7 +603,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
                  o_stop = carve(sizeof(int) * lanes),
                  o_bn = carve(sizeof(uint32_t) * (size_t)lanes * KMAX * 2), o_bv = carve(sizeof(double) * (size_t)lanes * KMAX * 2),
                  o_an = carve(sizeof(uint32_t) * (size_t)lanes * KMAX * 2), o_av = carve(sizeof(double) * (size_t)lanes * KMAX * 2),
-                 o_hand = carve(sizeof(BHandoff) * (size_t)lanes);
+                 o_hand = carve(sizeof(BHandoff) * (size_t)lanes), o_eoff = carve(sizeof(unsigned long long) * 2 * (size_t)lanes);
     ctl.reserve(cb);
     char *cp = (char *)ctl.p;
     // Pa (two buffers, by position parity), Pb and the per-run maxima of Pa
@@ -670,6 +724,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.ratio_lin = mc.ratio_lin;
         ma.topk = mc.topk;
         ma.err = (uint32_t *)(cp + o_err);
+        ma.eoff = (unsigned long long *)(cp + o_eoff);
         const bool st_on = W == 64;  // statistics of bwd_step<64> only (bench.py's roofline)
         LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock;
@@ -686,7 +741,8 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         }
         for (auto &e : m->cevent[wi])
             if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        hipStream_t s2 = m->cstream[wi];
+        // (PHMM_SERIAL_EMIT: the list kernels on the main stream, for profiling them alone)
+        hipStream_t s2 = std::getenv("PHMM_SERIAL_EMIT") ? s : m->cstream[wi];
         hipEvent_t *ev_col = &m->cevent[wi][0], *ev_emit = &m->cevent[wi][2];
         bool emitted[2] = {false, false};
         for (int pos = pos_max; pos >= 0; pos--) {
@@ -706,6 +762,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             launch_post_collect_w(W, ma, pos);
             HIP_CHECK(hipEventRecord(ev_col[par], s));
             HIP_CHECK(hipStreamWaitEvent(s2, ev_col[par], 0));
+            hipLaunchKernelGGL(emit_offsets, dim3(1), dim3(1024), 0, s2, ma, pos, lanes);
             hipLaunchKernelGGL(emit_dense_map, dim3(lanes, 2), dim3(BLOCK), 0, s2, ma, pos);
             HIP_CHECK(hipEventRecord(ev_emit[par], s2));
             emitted[par] = true;
