@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(BLOCK) post_collect(const DenseMapArgs ma, con
 // More than 400 nodes inside the ratio: keep the 400 best of the column (ties: lowest node id).
 // One 256-thread block: 8-bit radix select of the 400th-largest bit pattern (positive doubles
 // order like integers), then an ordered collect (everything above it, then ties in node order).
-__device__ int block_top_from_column(const double *col, int stride, int N, double thr, uint32_t *ids, double *val) {
+__device__ int block_top_radix(const double *col, int stride, int N, double thr, uint32_t *ids, double *val) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_k, s_wcnt[BLOCK / 64], s_n;
@@ -480,6 +480,114 @@ __global__ void __launch_bounds__(1024) emit_offsets(const DenseMapArgs ma, cons
     }
 }
 
+// The same selection in three passes over the column instead of ten.  A read whose first bases fit nowhere has
+// tens of thousands of nodes inside the ratio at its first positions, the column is strided by the read-group
+// width (a 64-byte sector per value), and the bwd_step two columns on waits for this column's plane: at 2.8 ms
+// a column two such reads cost cfg3 more than 10 ms per step.  Values inside the ratio span < 2^11 bins of
+// bits(v) >> shift: one histogram pass finds the bin of the 400th largest, one pass collects everything above
+// it plus the boundary bin (staged in LDS, normally a few dozen values), a rank-by-counting over the boundary
+// bin settles the rest (ties: lowest node id, as before).  A boundary bin beyond the staging room falls back to
+// the radix select.
+static constexpr int TOPH_BINS = 2048, TOPH_STAGE = 1024;
+__device__ int block_top_from_column(const double *col, int stride, int N, double thr, double vmax, uint32_t *ids, double *val) {
+    __shared__ unsigned int hist[TOPH_BINS];
+    __shared__ uint32_t bid[TOPH_STAGE];
+    __shared__ double bval[TOPH_STAGE];
+    __shared__ int s_bin, s_need, s_n, s_nb, s_wcnt[BLOCK / 64], s_wcnb[BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lo = (unsigned long long)__double_as_longlong(thr > 0.0 ? thr : 0.0);
+    const unsigned long long hi = (unsigned long long)__double_as_longlong(vmax);
+    const unsigned long long range = hi > lo ? hi - lo : 0ull;
+    int shift = 0;
+    while ((range >> shift) >= (unsigned long long)TOPH_BINS) shift++;
+    for (int h = tid; h < TOPH_BINS; h += BLOCK) hist[h] = 0u;
+    __syncthreads();
+    for (int k = tid; k < N; k += BLOCK) {
+        const double v = col[(size_t)k * stride];
+        if (!(v > thr)) continue;
+        const unsigned long long b = ((unsigned long long)__double_as_longlong(v) - lo) >> shift;
+        atomicAdd(&hist[b < (unsigned long long)TOPH_BINS ? (int)b : TOPH_BINS - 1], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int k = KMAX, d = TOPH_BINS - 1;
+        for (; d > 0; d--) {
+            if ((int)hist[d] >= k) break;
+            k -= (int)hist[d];
+        }
+        s_bin = d;    // bin of the KMAX-th largest value (or 0: fewer than KMAX qualify above it)
+        s_need = k;   // how many of that bin are wanted
+        s_n = 0;
+        s_nb = 0;
+    }
+    __syncthreads();
+    const int bstar = s_bin;
+    for (int base = 0; base < N; base += BLOCK) {
+        const int k = base + tid;
+        double v = 0.0;
+        bool take = false, edge = false;
+        if (k < N) {
+            v = col[(size_t)k * stride];
+            if (v > thr) {
+                unsigned long long b = ((unsigned long long)__double_as_longlong(v) - lo) >> shift;
+                if (b >= (unsigned long long)TOPH_BINS) b = TOPH_BINS - 1;
+                take = (int)b > bstar;
+                edge = (int)b == bstar;
+            }
+        }
+        const unsigned long long mk = __ballot(take), me = __ballot(edge);
+        if (lane == 0) {
+            s_wcnt[wave] = __popcll(mk);
+            s_wcnb[wave] = __popcll(me);
+        }
+        __syncthreads();
+        int p = s_n + __popcll(mk & ((1ull << lane) - 1ull)), pb = s_nb + __popcll(me & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) {
+            p += s_wcnt[w];
+            pb += s_wcnb[w];
+        }
+        if (take && p < KMAX) {
+            ids[p] = (uint32_t)k;
+            val[p] = v;
+        }
+        if (edge && pb < TOPH_STAGE) {
+            bid[pb] = (uint32_t)k;
+            bval[pb] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = s_n, tb = s_nb;
+            for (int w = 0; w < BLOCK / 64; w++) {
+                t += s_wcnt[w];
+                tb += s_wcnb[w];
+            }
+            s_n = t;
+            s_nb = tb;
+        }
+        __syncthreads();
+    }
+    const int nabove = s_n, nb = s_nb, need = s_need;
+    if (nb > TOPH_STAGE) return block_top_radix(col, stride, N, thr, ids, val);  // (uniform: every thread sees s_nb)
+    // the `need` largest of the boundary bin, ties by node id
+    __syncthreads();
+    for (int j = tid; j < nb; j += BLOCK) {
+        const double v = bval[j];
+        const uint32_t id = bid[j];
+        int rank = 0;
+        for (int q = 0; q < nb; q++) {
+            const double u = bval[q];
+            rank += (u > v) || (u == v && bid[q] < id);
+        }
+        if (rank < need && nabove + rank < KMAX) {
+            ids[nabove + rank] = id;
+            val[nabove + rank] = v;
+        }
+    }
+    __syncthreads();
+    const int tot = nabove + (nb < need ? nb : need);
+    return tot < KMAX ? tot : KMAX;
+}
+
 // one wave per (lane, which): sort the collected nodes and write the mapping record
 __global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, const int pos) {
     __shared__ uint32_t ids[KMAX];
@@ -503,7 +611,7 @@ __global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, c
     if (c > KMAX) {
         const double *P = (which == 0 ? a.Pa : a.Pb) + (size_t)g * a.N * ma.W + r;
         const double vmax = __longlong_as_double((long long)a.pmax[((size_t)g * (a.Lc + 1) + mi) * ma.W + r]);
-        n = block_top_from_column(P, ma.W, a.N, vmax * ma.ratio_lin, ids, val);
+        n = block_top_from_column(P, ma.W, a.N, vmax * ma.ratio_lin, vmax, ids, val);
     } else {
         const uint32_t *cn = (which == 0 ? ma.candA_node : ma.candB_node) + (size_t)gi * KMAX;
         const double *cv = (which == 0 ? ma.candA_val : ma.candB_val) + (size_t)gi * KMAX;
