@@ -282,6 +282,7 @@ struct DenseMapArgs {
     int topk;
     uint32_t *err;
     unsigned long long *eoff;  // [2][lanes] record offsets of the column being emitted (emit_offsets)
+    int force_radix;           // tests: take the radix fallback of block_top_from_column
 };
 
 template <int W>
@@ -489,7 +490,9 @@ __global__ void __launch_bounds__(1024) emit_offsets(const DenseMapArgs ma, cons
 // bin settles the rest (ties: lowest node id, as before).  A boundary bin beyond the staging room falls back to
 // the radix select.
 static constexpr int TOPH_BINS = 2048, TOPH_STAGE = 1024;
-__device__ int block_top_from_column(const double *col, int stride, int N, double thr, double vmax, uint32_t *ids, double *val) {
+__device__ int block_top_from_column(const double *col, int stride, int N, double thr, double vmax, uint32_t *ids, double *val,
+                                     bool force_radix) {
+    if (force_radix) return block_top_radix(col, stride, N, thr, ids, val);
     __shared__ unsigned int hist[TOPH_BINS];
     __shared__ uint32_t bid[TOPH_STAGE];
     __shared__ double bval[TOPH_STAGE];
@@ -611,7 +614,7 @@ __global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, c
     if (c > KMAX) {
         const double *P = (which == 0 ? a.Pa : a.Pb) + (size_t)g * a.N * ma.W + r;
         const double vmax = __longlong_as_double((long long)a.pmax[((size_t)g * (a.Lc + 1) + mi) * ma.W + r]);
-        n = block_top_from_column(P, ma.W, a.N, vmax * ma.ratio_lin, vmax, ids, val);
+        n = block_top_from_column(P, ma.W, a.N, vmax * ma.ratio_lin, vmax, ids, val, ma.force_radix != 0);
     } else {
         const uint32_t *cn = (which == 0 ? ma.candA_node : ma.candB_node) + (size_t)gi * KMAX;
         const double *cv = (which == 0 ? ma.candA_val : ma.candB_val) + (size_t)gi * KMAX;
@@ -833,6 +836,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.topk = mc.topk;
         ma.err = (uint32_t *)(cp + o_err);
         ma.eoff = (unsigned long long *)(cp + o_eoff);
+        ma.force_radix = std::getenv("PHMM_FORCE_RADIX") ? 1 : 0;
         const bool st_on = W == 64;  // statistics of bwd_step<64> only (bench.py's roofline)
         LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock;

@@ -676,3 +676,23 @@ def test_generic_frontier_class_matches_oracle(gpu_lib, oracle, no_lean, monkeyp
     omp, onf = om.generate_mappings(reads, None, True, n_threads=8)
     _compare_mappings(reads, mp.arrays(), omp)
     assert np.max(np.abs(nf - onf)) < 1e-6 * len(reads)
+
+
+def test_overfull_dense_column_selection_paths_agree(gpu_lib, monkeypatch):
+    """A read that fits nowhere keeps more than 400 nodes inside the score ratio in the dense head of its mapping:
+    the 400 best come from a histogram pass + boundary-bin ranking, with an eight-pass radix select as fallback
+    (mapping_flow.hip: block_top_from_column).  Both must give the same lists."""
+    arrays, sg = small_dbg_model(5000, 12, 0.01, seed=17, min_copy_num=1)
+    rng = np.random.default_rng(5)
+    junk = [bytes(rng.choice(list(b"ACGT"), size=15).tolist()) for _ in range(3)]  # short: nothing narrows them down
+    reads = D.sample_reads(arrays, 10 ** 9, 100, seed=3, max_reads=5) + junk
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    mp1, nf1 = gm.generate_mappings(rc, None, True)
+    po1, nd1, lp1 = mp1.arrays()
+    assert np.diff(po1.astype(np.int64)).max() == 400  # the junk reads fill the list capacity
+    monkeypatch.setenv("PHMM_FORCE_RADIX", "1")
+    mp2, nf2 = gm.generate_mappings(rc, None, True)
+    po2, nd2, lp2 = mp2.arrays()
+    assert np.array_equal(po1, po2) and np.array_equal(nd1, nd2) and np.array_equal(lp1, lp2)
+    assert np.array_equal(nf1, nf2)
