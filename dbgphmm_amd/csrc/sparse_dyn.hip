@@ -418,7 +418,13 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         HIP_CHECK(hipStreamSynchronize(current_stream()));
         int target = chunk_groups;
         if (target == 0) target = n_workers > 1 ? std::max(4, (plan.ng_total + 3 * n_workers - 1) / (3 * n_workers)) : plan.ng_total;
-        const uint64_t limit = limit_total / (uint64_t)n_workers;
+        uint64_t limit = limit_total / (uint64_t)n_workers;
+        if (&dst == &side_queue) {
+            // a plan of deferred reads runs BESIDE the main plan, whose tables hold most of the memory: its chunks
+            // are cut to what is free now (half of it: record pools and list buffers come on top)
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess) limit = std::min<uint64_t>(limit, (uint64_t)fr / 2);
+        }
         int g0 = 0;
         while (g0 < plan.ng_total) {
             // dense columns kept: at most n_warmup (+1 so that the launch that writes d of the last
