@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libphmm_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PHMM_OK, PHMM_EINVAL, PHMM_ENODEVICE, PHMM_ENOMEM, PHMM_ECAPACITY, PHMM_EINTERNAL = 0, -1, -2, -3, -4, -5
+PHMM_READ_DEFERRED, PHMM_READ_WIDE_FRONTIER, PHMM_READ_FORCED_SWITCH = 1, 2, 4  # phmm_reads_last_call_info flags
 
 
 class PhmmError(RuntimeError):
@@ -48,6 +49,9 @@ def lib():
         "phmm_set_device": (i32, [i32]),
         "phmm_set_stream": (i32, [vp]),
         "phmm_set_workspace_limit": (i32, [u64]),
+        "phmm_release_workspace": (i32, []),
+        "phmm_workspace_bytes": (u64, []),
+        "phmm_reads_last_call_info": (i32, [vp, vp, vp]),
         "phmm_params_new": (i32, [dbl, dbl, dbl, dbl, i64, i64, vp]),
         "phmm_params_uniform": (i32, [dbl, vp]),
         "phmm_model_create": (i32, [u32, u32, vp, vp, vp, vp, vp, vp, P(vp)]),
@@ -92,7 +96,7 @@ def lib():
 
 DECLARED_SYMBOLS = [
     "phmm_last_error", "phmm_version", "phmm_device_count", "phmm_set_device", "phmm_set_stream",
-    "phmm_set_workspace_limit", "phmm_params_new", "phmm_params_uniform", "phmm_model_create",
+    "phmm_set_workspace_limit", "phmm_release_workspace", "phmm_workspace_bytes", "phmm_reads_last_call_info", "phmm_params_new", "phmm_params_uniform", "phmm_model_create",
     "phmm_model_set_probs", "phmm_model_set_params", "phmm_model_n_nodes", "phmm_model_n_edges",
     "phmm_model_destroy", "phmm_reads_create", "phmm_reads_count", "phmm_reads_total_bases",
     "phmm_reads_destroy", "phmm_run_dense", "phmm_run_dense_edges", "phmm_q_score_exact", "phmm_run_sparse", "phmm_full_prob_sparse_backward", "phmm_backward_sparse_tables", "phmm_dense_tables", "phmm_mappings_create",

@@ -61,13 +61,49 @@ void trace(const char *tag) {
     last = now;
 }
 
-uint64_t table_budget(size_t owned) {
+uint64_t table_budget(const DevicePool &pool, uint64_t reserve) {
     if (g_ws_limit) return g_ws_limit;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)16 << 30;
     double frac = 0.9;
     if (const char *e = std::getenv("PHMM_MEM_FRACTION")) frac = std::min(0.95, std::max(0.1, std::atof(e)));
-    return (uint64_t)(frac * (double)(fr + owned));
+    const double b = frac * (double)(fr + pool.owned_table_bytes()) - (double)reserve;
+    return (uint64_t)std::max(b, 64.0 * 1024 * 1024);
+}
+
+// ---------------------------------------------------------------- per-device workspace pool
+static std::mutex g_pool_mu;
+static DevicePool *g_pools[64] = {};
+DevicePool &device_pool() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) PHMM_THROW(PHMM_ENODEVICE, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pools[dev]) {
+        g_pools[dev] = new DevicePool();  // never destroyed: the HIP runtime may be gone by static-destructor time
+        g_pools[dev]->device = dev;
+    }
+    return *g_pools[dev];
+}
+void DevicePool::release() {
+    for (auto &w : wsets) w.release();
+    ws_out.release();
+    for (auto &ws : wstream)
+        if (ws) {
+            (void)hipStreamDestroy(ws);
+            ws = nullptr;
+        }
+    for (auto &ws : cstream)
+        if (ws) {
+            (void)hipStreamDestroy(ws);
+            ws = nullptr;
+        }
+    for (auto &we : cevent)
+        for (auto &e : we)
+            if (e) {
+                (void)hipEventDestroy(e);
+                e = nullptr;
+            }
 }
 
 void copy_out(void *dst, const void *src_dev, size_t bytes) {
@@ -122,6 +158,20 @@ template <class F> static int guarded(F &&f) {
     }
 }
 
+// compute entry points: one call at a time per device (the workspaces are the device's), on the model's device
+template <class F> static int guarded_on(phmm_model *m, F &&f) {
+    if (!m || !m->pool) return fail(PHMM_EINVAL, "NULL model");
+    std::lock_guard<std::recursive_mutex> lk(m->pool->call_mu);
+    return guarded([&] {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        if (dev != m->pool->device)
+            PHMM_THROW(PHMM_EINVAL, "the model lives on device " + std::to_string(m->pool->device) +
+                                        " but this thread's device is " + std::to_string(dev) + " (phmm_set_device)");
+        f();
+    });
+}
+
 static void check_params(const phmm_params *p) {
     if (!p) PHMM_THROW(PHMM_EINVAL, "params is NULL");
     // params.rs:81-83
@@ -147,6 +197,8 @@ static void require_device() {
 }  // namespace phmm
 
 using namespace phmm;
+
+phmm::WorkSet &phmm_model::wset() { return pool->wsets[phmm::workset_index()]; }
 
 extern "C" {
 
@@ -234,6 +286,7 @@ int phmm_model_create(uint32_t N, uint32_t E, const uint8_t *emission, const dou
             if (std::isnan(trans_logp[e]) || trans_logp[e] > 1e-9) PHMM_THROW(PHMM_EINVAL, "trans_logp > 0 or NaN");
         require_device();
         m = new phmm_model();
+        m->pool = &device_pool();
         m->N = N;
         m->E = E;
         m->params = *params;
@@ -251,7 +304,7 @@ int phmm_model_create(uint32_t N, uint32_t E, const uint8_t *emission, const dou
 }
 
 int phmm_model_set_probs(phmm_model *m, const double *init_logp, const double *trans_logp) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !init_logp || (m->E && !trans_logp)) PHMM_THROW(PHMM_EINVAL, "NULL argument");
         m->init_logp.assign(init_logp, init_logp + m->N);
         m->trans_logp.assign(trans_logp, trans_logp + m->E);
@@ -259,7 +312,7 @@ int phmm_model_set_probs(phmm_model *m, const double *init_logp, const double *t
     });
 }
 int phmm_model_set_params(phmm_model *m, const phmm_params *params) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m) PHMM_THROW(PHMM_EINVAL, "NULL model");
         check_params(params);
         m->params = *params;
@@ -269,16 +322,22 @@ int phmm_model_set_params(phmm_model *m, const phmm_params *params) {
 }
 uint32_t phmm_model_n_nodes(const phmm_model *m) { return m ? m->N : 0; }
 uint32_t phmm_model_n_edges(const phmm_model *m) { return m ? m->E : 0; }
-void phmm_model_destroy(phmm_model *m) {
-    if (!m) return;
-    for (auto &ws : m->wstream)
-        if (ws) (void)hipStreamDestroy(ws);
-    for (auto &ws : m->cstream)
-        if (ws) (void)hipStreamDestroy(ws);
-    for (auto &we : m->cevent)
-        for (auto &e : we)
-            if (e) (void)hipEventDestroy(e);
-    delete m;
+void phmm_model_destroy(phmm_model *m) { delete m; }  // (the workspaces belong to the device: phmm_release_workspace)
+
+int phmm_release_workspace(void) {
+    return guarded([&] {
+        require_device();
+        DevicePool &pool = device_pool();
+        std::lock_guard<std::recursive_mutex> lk(pool.call_mu);
+        HIP_CHECK(hipDeviceSynchronize());
+        pool.release();
+    });
+}
+uint64_t phmm_workspace_bytes(void) {
+    if (phmm_device_count() <= 0) return 0;
+    uint64_t b = 0;
+    (void)guarded([&] { b = device_pool().owned_bytes(); });
+    return b;
 }
 
 int phmm_reads_create(const uint8_t *bases, const uint64_t *offsets, uint64_t R, phmm_reads **out) {
@@ -306,10 +365,19 @@ int phmm_reads_create(const uint8_t *bases, const uint64_t *offsets, uint64_t R,
 }
 uint64_t phmm_reads_count(const phmm_reads *r) { return r ? r->R : 0; }
 uint64_t phmm_reads_total_bases(const phmm_reads *r) { return r ? r->total : 0; }
+int phmm_reads_last_call_info(const phmm_reads *r, uint16_t *out_dense_columns, uint32_t *out_flags) {
+    return guarded([&] {
+        if (!r) PHMM_THROW(PHMM_EINVAL, "NULL reads");
+        if (r->warm_hint.size() != r->R || r->last_flags.size() != r->R)
+            PHMM_THROW(PHMM_EINVAL, "no adaptive-sparse call (use_max_ratio = 1, no mappings) has run on these reads yet");
+        if (out_dense_columns) std::memcpy(out_dense_columns, r->warm_hint.data(), sizeof(uint16_t) * r->R);
+        if (out_flags) std::memcpy(out_flags, r->last_flags.data(), sizeof(uint32_t) * r->R);
+    });
+}
 void phmm_reads_destroy(phmm_reads *r) { delete r; }
 
 int phmm_run_dense(phmm_model *m, const phmm_reads *reads, double *lf, double *lb, double *nf) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
         if (reads->R == 0) {
             if (nf) {
@@ -325,7 +393,7 @@ int phmm_run_dense(phmm_model *m, const phmm_reads *reads, double *lf, double *l
 }
 
 int phmm_run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_ef, double *out_if) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
         if (reads->R == 0) return;
         for (uint64_t r = 0; r < reads->R; r++)
@@ -335,7 +403,7 @@ int phmm_run_dense_edges(phmm_model *m, const phmm_reads *reads, double *out_lf,
 }
 
 int phmm_full_prob_sparse_backward(phmm_model *m, const phmm_reads *reads, double *out_logp, double *out_total) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
         if (reads->R == 0) {
             const double zero = 0.0;  // empty product = Prob::one()
@@ -349,7 +417,7 @@ int phmm_full_prob_sparse_backward(phmm_model *m, const phmm_reads *reads, doubl
 }
 
 int phmm_run_sparse(phmm_model *m, const phmm_reads *reads, double *out_lf, double *out_lb, double *out_nf) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
         if (reads->R == 0) {
             if (out_nf) {
@@ -368,7 +436,7 @@ int phmm_run_sparse(phmm_model *m, const phmm_reads *reads, double *out_lf, doub
 
 int phmm_backward_sparse_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *b_m, double *b_i, double *b_d,
                                 double *b_scal, uint8_t *is_dense) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !read) PHMM_THROW(PHMM_EINVAL, "NULL model or read");
         if (len == 0) PHMM_THROW(PHMM_EINVAL, "empty read");
         backward_sparse_tables(m, read, len, b_m, b_i, b_d, b_scal, is_dense);
@@ -398,7 +466,7 @@ int phmm_q_score_exact(const phmm_model *m, const double *edge_freq, const doubl
 
 int phmm_dense_tables(phmm_model *m, const uint8_t *read, uint64_t len, double *f_m, double *f_i, double *f_d,
                       double *f_scal, double *b_m, double *b_i, double *b_d, double *b_scal) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !read) PHMM_THROW(PHMM_EINVAL, "NULL model or read");
         if (len == 0) PHMM_THROW(PHMM_EINVAL, "empty read");
         dense_tables(m, read, len, f_m, f_i, f_d, f_scal, b_m, b_i, b_d, b_scal);
@@ -487,7 +555,7 @@ static void check_mapping_nodes(const phmm_model *m, const phmm_mappings *mp, co
 
 int phmm_full_prob_reads(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, int use_max_ratio,
                          double *out_logp, double *out_total) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !reads) PHMM_THROW(PHMM_EINVAL, "NULL model or reads");
         if (reads->R == 0) {
             const double zero = 0.0;  // empty product = Prob::one()
@@ -506,7 +574,7 @@ int phmm_full_prob_reads(phmm_model *m, const phmm_reads *reads, const phmm_mapp
 int phmm_full_prob_reads_candidates(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
                                     const double *init_logp, const double *trans_logp, double *out_logp,
                                     double *out_total) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !reads || !mp) PHMM_THROW(PHMM_EINVAL, "NULL model, reads or mappings");
         if (n_cand == 0) return;
         if (!init_logp || (m->E && !trans_logp)) PHMM_THROW(PHMM_EINVAL, "NULL candidate arrays");
@@ -518,7 +586,7 @@ int phmm_full_prob_reads_candidates(phmm_model *m, const phmm_reads *reads, cons
 int phmm_full_prob_reads_copy_nums(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, uint32_t n_cand,
                                    const uint32_t *copy_nums, uint32_t min_copy_num, double *out_logp,
                                    double *out_total) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !reads || !mp) PHMM_THROW(PHMM_EINVAL, "NULL model, reads or mappings");
         if (n_cand == 0) return;
         if (!copy_nums) PHMM_THROW(PHMM_EINVAL, "NULL copy numbers");
@@ -531,7 +599,7 @@ int phmm_full_prob_reads_copy_nums(phmm_model *m, const phmm_reads *reads, const
 int phmm_mappings_map_nodes(phmm_model *model_after, const phmm_reads *reads, const phmm_mappings *mp,
                             const uint32_t *map_off, const uint32_t *map_nodes, uint32_t n_nodes_before,
                             phmm_mappings **out) {
-    return guarded([&] {
+    return guarded_on(model_after, [&] {
         if (!model_after || !reads || !mp || !map_off || !out) PHMM_THROW(PHMM_EINVAL, "NULL argument");
         *out = nullptr;
         if (mp->R != reads->R || mp->total_pos != reads->total) PHMM_THROW(PHMM_EINVAL, "mappings do not belong to these reads");
@@ -545,7 +613,7 @@ int phmm_mappings_map_nodes(phmm_model *model_after, const phmm_reads *reads, co
 
 int phmm_generate_mappings(phmm_model *m, const phmm_reads *reads, const phmm_mappings *mp, int use_max_ratio,
                            phmm_mappings **out, double *out_node_freq) {
-    return guarded([&] {
+    return guarded_on(m, [&] {
         if (!m || !reads || !out) PHMM_THROW(PHMM_EINVAL, "NULL argument");
         *out = nullptr;
         if (reads->R == 0) PHMM_THROW(PHMM_EINVAL, "no reads");

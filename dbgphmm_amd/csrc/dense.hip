@@ -1172,7 +1172,7 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
     st = CallStats();
     const int W = plan.W;
     const size_t NW = (size_t)m->N * W;
-    const uint64_t limit = table_budget(m->wset().tables.bytes);
+    const uint64_t limit = table_budget(*m->pool);
 
     DenseArgs base{};
     fill_model_args(base, m);
@@ -1184,7 +1184,7 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
 
     // per-read results gathered on the host in the caller's order
     std::vector<double> lf(R), lb(want_b ? R : 0);
-    DevBuf &nf_dev = m->ws_out;
+    DevBuf &nf_dev = m->pool->ws_out;
     if (want_freq) {
         nf_dev.reserve(sizeof(double) * m->N);
         HIP_CHECK(hipMemsetAsync(nf_dev.p, 0, sizeof(double) * m->N, s));

@@ -845,17 +845,17 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         // the column where more than 400 nodes are inside the ratio) runs on a side stream under the next
         // columns' bwd_step; the emit-prob plane is double-buffered by position parity for that.
         const int wi = workset_index();
-        if (!m->cstream[wi]) {
+        if (!m->pool->cstream[wi]) {
             // lowest priority: the list kernels fill the gaps, the HBM-bound bwd_step keeps the machine
             int least = 0, greatest = 0;
             HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_CHECK(hipStreamCreateWithPriority(&m->cstream[wi], hipStreamNonBlocking, least));
+            HIP_CHECK(hipStreamCreateWithPriority(&m->pool->cstream[wi], hipStreamNonBlocking, least));
         }
-        for (auto &e : m->cevent[wi])
+        for (auto &e : m->pool->cevent[wi])
             if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         // (PHMM_SERIAL_EMIT: the list kernels on the main stream, for profiling them alone)
-        hipStream_t s2 = std::getenv("PHMM_SERIAL_EMIT") ? s : m->cstream[wi];
-        hipEvent_t *ev_col = &m->cevent[wi][0], *ev_emit = &m->cevent[wi][2];
+        hipStream_t s2 = std::getenv("PHMM_SERIAL_EMIT") ? s : m->pool->cstream[wi];
+        hipEvent_t *ev_col = &m->pool->cevent[wi][0], *ev_emit = &m->pool->cevent[wi][2];
         bool emitted[2] = {false, false};
         for (int pos = pos_max; pos >= 0; pos--) {
             const int par = pos & 1;
@@ -1075,7 +1075,7 @@ void generate_mappings_sparse(phmm_model *m, const phmm_reads *reads, phmm_mappi
 // then the MAX_ACTIVE_NODES most probable in descending order.  node_map arrives as a CSR over the OLD nodes.
 // One wave per position; the entries are taken in list order (lanes = the images of one node), so every sum
 // has a fixed order.
-static constexpr int MN_HASH = 4096;  // >= 2 x (400 entries x 5 images)
+static constexpr int MN_HASH = 4096, MN_CELLS = MN_HASH / 2;
 struct MapNodesArgs {
     const uint64_t *pos_off;
     const uint32_t *nodes;
@@ -1086,67 +1086,113 @@ struct MapNodesArgs {
     RecPool out;
     uint32_t *err;  // [1]
 };
+// The images of one position are merged in an LDS hash (MN_CELLS distinct images at most).  A position with more
+// than that -- 400 entries x a fan-out above 5, far from anything MultiDbg produces -- is done in P passes over
+// the key classes `image % P`, each pass folding its cells into a running top-400 list; a class that still
+// overflows doubles P and the position starts again (n_new / P <= MN_CELLS ends that for good).  Nothing here
+// can spin: probes are bounded by the table never being more than half full + one round of 64 inserts.
 __global__ void __launch_bounds__(64) map_nodes_kernel(const MapNodesArgs a) {
     __shared__ uint32_t keys[MN_HASH];
     __shared__ double acc[MN_HASH];
-    __shared__ uint16_t cells[MN_HASH / 2];  // claimed cells in insertion order
+    __shared__ uint16_t cells[MN_CELLS + 64];  // claimed cells in insertion order
+    __shared__ uint32_t run_id[2][PHMM_MAX_ACTIVE_NODES];
+    __shared__ double run_v[2][PHMM_MAX_ACTIVE_NODES];
     __shared__ int ncell;
     const uint64_t p = blockIdx.x;
     const int lane = threadIdx.x;
-    for (int h = lane; h < MN_HASH; h += 64) keys[h] = H_EMPTY;
-    if (lane == 0) ncell = 0;
-    __syncthreads();
     const uint64_t o0 = a.pos_off[p], o1 = a.pos_off[p + 1];
     uint32_t bad = 0;
-    for (uint64_t j = o0; j < o1; j++) {
+    // how many images this position has at most (repeats included)
+    unsigned long long total = 0;
+    for (uint64_t j = o0 + lane; j < o1; j += 64) {
         const uint32_t node = a.nodes[j];
-        if (node >= a.n_old) {
-            bad = 1;
-            continue;
-        }
-        const uint32_t m0 = a.map_off[node], m1 = a.map_off[node + 1];
-        const uint32_t len = m1 - m0;
-        const double v = exp(a.logp[j]) / (double)(len ? len : 1);
-        for (uint32_t q0 = 0; q0 < len; q0 += 64) {
-            const uint32_t q = q0 + lane;
-            int cell = -1;
-            bool fresh = false;
-            if (q < len) {
-                const uint32_t key = a.map_nodes[m0 + q];
-                if (key >= a.n_new) bad = 1;
-                else {
-                    uint32_t h = (key * 2654435761u) >> 20;
-                    for (;;) {
-                        const uint32_t old = atomicCAS(&keys[h], H_EMPTY, key);
-                        if (old == H_EMPTY) {
-                            fresh = true;
-                            acc[h] = 0.0;
-                            break;
+        if (node >= a.n_old) bad = 1;
+        else total += a.map_off[node + 1] - a.map_off[node];
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        total += __shfl_xor(total, off);
+        bad |= (uint32_t)__shfl_xor((int)bad, off);
+    }
+    uint32_t P = total <= (unsigned long long)MN_CELLS ? 1u : (uint32_t)((total + MN_CELLS / 2 - 1) / (MN_CELLS / 2));
+    int run_n = 0, cur = 0;
+    for (bool done = bad != 0; !done;) {
+        run_n = 0;
+        cur = 0;
+        bool overflow = false;
+        for (uint32_t cls = 0; cls < P && !overflow; cls++) {
+            for (int h = lane; h < MN_HASH; h += 64) keys[h] = H_EMPTY;
+            if (lane == 0) ncell = 0;
+            __syncthreads();
+            for (uint64_t j = o0; j < o1 && !overflow; j++) {
+                const uint32_t node = a.nodes[j];
+                const uint32_t m0 = a.map_off[node], m1 = a.map_off[node + 1];
+                const uint32_t len = m1 - m0;
+                const double v = exp(a.logp[j]) / (double)(len ? len : 1);
+                for (uint32_t q0 = 0; q0 < len && !overflow; q0 += 64) {
+                    const uint32_t q = q0 + lane;
+                    int cell = -1;
+                    bool fresh = false;
+                    if (q < len) {
+                        const uint32_t key = a.map_nodes[m0 + q];
+                        if (key >= a.n_new) bad = 1;
+                        else if (P == 1 || key % P == cls) {
+                            uint32_t h = (key * 2654435761u) >> 20;
+                            for (int probe = 0; probe < MN_HASH; probe++) {
+                                const uint32_t old = atomicCAS(&keys[h], H_EMPTY, key);
+                                if (old == H_EMPTY) {
+                                    fresh = true;
+                                    acc[h] = 0.0;
+                                }
+                                if (old == H_EMPTY || old == key) {
+                                    cell = (int)h;
+                                    break;
+                                }
+                                h = (h + 1) & (MN_HASH - 1);
+                            }
                         }
-                        if (old == key) break;
-                        h = (h + 1) & (MN_HASH - 1);
                     }
-                    cell = (int)h;
+                    const unsigned long long fm = __ballot(fresh);
+                    const int base = ncell;
+                    if (fresh) cells[base + __popcll(fm & ((1ull << lane) - 1ull))] = (uint16_t)cell;
+                    __syncthreads();
+                    if (lane == 0) ncell = base + __popcll(fm);
+                    // (images of one node are distinct in a well-formed map; a repeated image still adds up, just
+                    // through an atomic)
+                    if (cell >= 0) atomicAdd(&acc[cell], v);
+                    __syncthreads();
+                    overflow = ncell > MN_CELLS;  // (uniform: every lane reads the same word)
                 }
             }
-            const unsigned long long fm = __ballot(fresh);
-            const int base = ncell;
-            if (fresh) {
-                const int s = base + __popcll(fm & ((1ull << lane) - 1ull));
-                if (s < MN_HASH / 2) cells[s] = (uint16_t)cell;
-                else bad = 2;
+            if (overflow) break;
+            // fold this class into the running list: rank among (cells of the pass) + (running list), keep 400
+            const int n = ncell, rn = run_n;
+            const int nxt = cur ^ 1;
+            for (int j = lane; j < n + rn; j += 64) {
+                const double v = j < n ? acc[cells[j]] : run_v[cur][j - n];
+                const uint32_t id = j < n ? keys[cells[j]] : run_id[cur][j - n];
+                int rank = 0;
+                for (int q = 0; q < n; q++) {
+                    const double u = acc[cells[q]];
+                    rank += (u > v) || (u == v && keys[cells[q]] < id);
+                }
+                for (int q = 0; q < rn; q++) {
+                    const double u = run_v[cur][q];
+                    rank += (u > v) || (u == v && run_id[cur][q] < id);
+                }
+                if (rank < PHMM_MAX_ACTIVE_NODES) {
+                    run_id[nxt][rank] = id;
+                    run_v[nxt][rank] = v;
+                }
             }
             __syncthreads();
-            if (lane == 0) ncell = base + __popcll(fm);
-            // (images of one node are distinct in a well-formed map; a repeated image still adds up, just
-            // through an atomic)
-            if (cell >= 0) atomicAdd(&acc[cell], v);
-            __syncthreads();
+            run_n = n + rn < PHMM_MAX_ACTIVE_NODES ? n + rn : PHMM_MAX_ACTIVE_NODES;
+            cur = nxt;
         }
+        for (int off = 32; off >= 1; off >>= 1) bad |= (uint32_t)__shfl_xor((int)bad, off);
+        if (overflow && !bad && P < a.n_new) P *= 2;  // (P >= n_new: one key per class, cannot overflow)
+        else done = true;
     }
-    for (int off = 32; off >= 1; off >>= 1) bad |= (uint32_t)__shfl_xor((int)bad, off);
-    const int n = ncell < MN_HASH / 2 ? ncell : MN_HASH / 2;
-    const int keep = n < PHMM_MAX_ACTIVE_NODES ? n : PHMM_MAX_ACTIVE_NODES;
+    const int keep = run_n;
     const uint64_t idb = (uint64_t)((keep + 1) & ~1) * 4;
     const uint64_t bytes = 8 + idb + (uint64_t)keep * 8;
     const uint64_t o = pool_alloc(a.out, bytes);
@@ -1163,18 +1209,10 @@ __global__ void __launch_bounds__(64) map_nodes_kernel(const MapNodesArgs a) {
     }
     uint32_t *oid = (uint32_t *)(rec + 8);
     double *olp = (double *)(rec + 8 + idb);
-    for (int j = lane; j < n; j += 64) {
-        const double v = acc[cells[j]];
-        const uint32_t id = keys[cells[j]];
-        int rank = 0;
-        for (int q = 0; q < n; q++) {
-            const double u = acc[cells[q]];
-            rank += (u > v) || (u == v && keys[cells[q]] < id);
-        }
-        if (rank < keep) {
-            oid[rank] = id;
-            olp[rank] = v > 0.0 ? log(v) : -INFINITY;
-        }
+    for (int j = lane; j < keep; j += 64) {
+        const double v = run_v[cur][j];
+        oid[j] = run_id[cur][j];
+        olp[j] = v > 0.0 ? log(v) : -INFINITY;
     }
 }
 
@@ -1222,7 +1260,6 @@ void mappings_map_nodes(phmm_model *m, const phmm_reads *reads, const phmm_mappi
     HIP_CHECK(hipMemcpyAsync(&herr, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     if (herr & 1) PHMM_THROW(PHMM_EINVAL, "map_nodes: a node id is out of range");
-    if (herr & 2) PHMM_THROW(PHMM_ECAPACITY, "map_nodes: more than 2048 image nodes at one read position");
     if (herr & 4) PHMM_THROW(PHMM_EINTERNAL, "map_nodes: output pool exhausted");
     std::vector<double> lf = mp_in->read_logp;
     if (lf.size() != reads->R) lf.assign(reads->R, 0.0);

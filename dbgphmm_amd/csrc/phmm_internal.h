@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,8 +42,10 @@ struct ThreadContext {
 ThreadContext capture_thread_context();
 void adopt_thread_context(const ThreadContext &c, hipStream_t stream, int workset);
 uint64_t workspace_limit();
-// DP-table budget of a call on model buffers that already hold `owned` bytes
-uint64_t table_budget(size_t owned);
+struct DevicePool;
+// DP-table budget of a call: PHMM_MEM_FRACTION (0.9) of what is free plus the pool's own tables (they are
+// re-allocated), less `reserve` bytes the call's other buffers still have to grow by
+uint64_t table_budget(const DevicePool &pool, uint64_t reserve = 0);
 
 // ---------------------------------------------------------------- device buffers
 struct DevBuf {
@@ -72,6 +75,47 @@ struct DevBuf {
 };
 // copy device -> (host or device) destination
 void copy_out(void *dst, const void *src_dev, size_t bytes);
+
+// ---------------------------------------------------------------- per-device workspace pool
+// One set of grow-only buffers per pipeline worker (sparse_dyn.hip runs chunks of read groups concurrently on
+// their own streams); the API thread and single-stream paths use set 0.  aux[] = per-call scratch kept across
+// calls (no hipMalloc in the steady state).  phmm_release_workspace() gives everything back.
+struct WorkSet {
+    DevBuf tables, misc, aux[16];
+    size_t bytes() const {
+        size_t b = tables.bytes + misc.bytes;
+        for (const auto &a : aux) b += a.bytes;
+        return b;
+    }
+    void release() {
+        tables.release();
+        misc.release();
+        for (auto &a : aux) a.release();
+    }
+};
+static constexpr int MAX_WORKERS = 4;
+struct DevicePool {
+    int device = 0;
+    std::recursive_mutex call_mu;  // compute calls on one device run one at a time (any handle, any thread)
+    WorkSet wsets[MAX_WORKERS];
+    hipStream_t wstream[MAX_WORKERS] = {};  // worker streams, created on first use
+    hipStream_t cstream[MAX_WORKERS] = {};  // per worker: side stream of the mapping-list kernels (mapping_flow.hip)
+    hipEvent_t cevent[MAX_WORKERS][4] = {};
+    DevBuf ws_out;
+    size_t owned_table_bytes() const {
+        size_t b = 0;
+        for (const auto &w : wsets) b += w.tables.bytes;
+        return b;
+    }
+    size_t owned_bytes() const {
+        size_t b = ws_out.bytes;
+        for (const auto &w : wsets) b += w.bytes();
+        return b;
+    }
+    void release();  // frees every buffer, stream and event (the device must be idle)
+};
+// the pool of the calling thread's current device (created on first use, never destroyed: HIP may be gone at exit)
+DevicePool &device_pool();
 
 // ---------------------------------------------------------------- linear-domain parameters
 // The kernels run in the (scaled) linear probability domain; see DESIGN.md.
@@ -194,25 +238,11 @@ struct phmm_model {
     std::vector<double> logib;  // forward InsBegin chain, log domain (forward.rs:541-545)
     phmm::ModelDev dev;
     double wf_ub_a = 0.0, wf_ub_b = 0.0;  // column total <= ub_a * max(m,i) + ub_b * p_ID * ib (model.cpp)
-    // grow-only workspaces
-    // One set per pipeline worker (sparse_dyn.hip runs chunks of read groups concurrently on their own
-    // streams); the API thread and single-stream paths use set 0.  aux[] = per-call scratch kept across
-    // calls (no hipMalloc in the steady state).
-    struct WorkSet {
-        phmm::DevBuf tables, misc, aux[16];
-    };
-    static constexpr int MAX_WORKERS = 4;
-    WorkSet wsets[MAX_WORKERS];
-    hipStream_t wstream[MAX_WORKERS] = {};  // worker streams, created on first use
-    hipStream_t cstream[MAX_WORKERS] = {};  // per worker: side stream of the mapping-list kernels (mapping_flow.hip)
-    hipEvent_t cevent[MAX_WORKERS][4] = {};
-    phmm::DevBuf ws_out;
-    WorkSet &wset() { return wsets[phmm::workset_index()]; }
-    size_t owned_table_bytes() const {
-        size_t b = 0;
-        for (const auto &w : wsets) b += w.tables.bytes;
-        return b;
-    }
+    // Workspaces (DP tables, record pools, per-call scratch) belong to the DEVICE, not to the model: every
+    // handle on a device shares one phmm::DevicePool, so a mapping model and a scoring model coexist
+    // (multi_dbg/posterior.rs:247-255, 609-630) without each sizing its own tables from what is free.
+    phmm::DevicePool *pool = nullptr;
+    phmm::WorkSet &wset();
 };
 
 struct phmm_reads {
@@ -228,6 +258,9 @@ struct phmm_reads {
     // a read group runs dense columns until its slowest read switches, and rows of 64 reads in which only a
     // few are still dense cost whole 64-byte sectors per live read.
     mutable std::vector<uint16_t> warm_hint;
+    // what the last adaptive-sparse call did with each read (phmm_reads_last_call_info; diagnostics / parity tests):
+    // PHMM_READ_* bits of include/phmm_amd.h
+    mutable std::vector<uint32_t> last_flags;
 };
 
 struct phmm_mappings {

@@ -629,7 +629,7 @@ void backward_sparse_impl(phmm_model *m, const uint8_t *bases, const uint64_t *o
     Plan plan = make_plan(m, &suf, tabs ? 1 : 0);
     const int W = plan.W;
     const size_t NW = (size_t)m->N * W;
-    const uint64_t limit = table_budget(m->wset().tables.bytes);
+    const uint64_t limit = table_budget(*m->pool);
     DenseArgs base{};
     fill_model_args(base, m);
     base.nblk = plan.nblk;
@@ -755,7 +755,7 @@ void run_sparse(phmm_model *m, const phmm_reads *reads, double *out_lf, double *
     const int W = plan.W;
     const size_t NW = (size_t)m->N * W;
     // (half of the table budget: the record pools of both directions and the second table buffer live beside it)
-    const uint64_t limit = table_budget(m->wset().tables.bytes) / 2;
+    const uint64_t limit = table_budget(*m->pool) / 2;
     DenseArgs base{};
     fill_model_args(base, m);
     base.nblk = plan.nblk;

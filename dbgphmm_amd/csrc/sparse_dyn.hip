@@ -352,6 +352,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     const phmm_params &prm = m->params;
     std::vector<double> lf(R, 0.0);
     std::vector<uint16_t> new_hint(R, 0);
+    std::vector<uint32_t> new_flags(R, 0);  // PHMM_READ_* (written by the chunk that owns the read; chunks are disjoint)
     upload_reads(reads);
 
     // ---- work items.  A plan is a grouping of reads (W per group, longest first); it is cut into
@@ -396,12 +397,30 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     // sparse waves that share the SIMDs with the dense kernels take bwd_step<64> from 4.0 to 2.9 TB/s;
     // until the frontier kernels are cheaper the pipeline stays opt-in (PHMM_WORKERS=2..4).
     int n_workers = 1;
-    if (const char *e = std::getenv("PHMM_WORKERS")) n_workers = std::max(1, std::min(phmm_model::MAX_WORKERS, std::atoi(e)));
+    if (const char *e = std::getenv("PHMM_WORKERS")) n_workers = std::max(1, std::min(MAX_WORKERS, std::atoi(e)));
     int64_t warm_cols = 18;  // dense columns kept per read group by the first plan
     if (const char *e = std::getenv("PHMM_WARM_COLS")) warm_cols = std::max(4, std::atoi(e));
     int chunk_groups = 0;  // 0: automatic
     if (const char *e = std::getenv("PHMM_CHUNK_GROUPS")) chunk_groups = std::max(0, std::atoi(e));
-    const uint64_t limit_total = table_budget(m->owned_table_bytes());
+    // Memory plan of the call, fixed HERE (nothing below reads the free-memory counter again): the pool's other
+    // buffers are grow-only and reused, so what they still have to grow by for this read set is set aside first --
+    // forward record pool (~1 KB per sparse position), mapping sink, control arrays; the emit-prob planes of the
+    // mapping flow scale with the read groups and are part of the per-group cost below.  Of the rest, 1/8 is the
+    // budget of the deferred reads' plan (it runs BESIDE the main plan on its own stream and workspace set).
+    uint64_t aux_need = 0;
+    {
+        const uint64_t est_fpool = reads->total * 1024 + R * 65536 + (1u << 20), est_meta = reads->total * 40,
+                       est_ctl = R * (uint64_t)(PHMM_MAX_ACTIVE_NODES * 12 * 5 + WF_CAP * 12 + 4096) + reads->total,
+                       est_sink = sink ? reads->total * 176 + R * 131072 + (1u << 21) : 0,
+                       est_sel = (uint64_t)256 * m->N * 12;
+        const uint64_t est = 2 * (est_fpool + est_meta + est_ctl) / (sink ? 1 : 2) + est_sink + est_sel;
+        uint64_t have = 0;
+        for (const auto &w : m->pool->wsets)
+            for (const auto &b : w.aux) have += b.bytes;
+        aux_need = est > have ? est - have : 0;
+    }
+    const uint64_t limit_total = table_budget(*m->pool, aux_need);
+    const uint64_t limit_side = limit_total / 8, limit_main = limit_total - limit_side;
 
     // cut a plan into items (caller holds `mu` or is the only thread)
     auto enqueue_plan = [&](std::unique_ptr<PlanCtx> pcu, std::deque<Item> &dst) {
@@ -418,19 +437,16 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         HIP_CHECK(hipStreamSynchronize(current_stream()));
         int target = chunk_groups;
         if (target == 0) target = n_workers > 1 ? std::max(4, (plan.ng_total + 3 * n_workers - 1) / (3 * n_workers)) : plan.ng_total;
-        uint64_t limit = limit_total / (uint64_t)n_workers;
-        if (&dst == &side_queue) {
-            // a plan of deferred reads runs BESIDE the main plan, whose tables hold most of the memory: its chunks
-            // are cut to what is free now (half of it: record pools and list buffers come on top)
-            size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess) limit = std::min<uint64_t>(limit, (uint64_t)fr / 2);
-        }
+        // a plan of deferred reads runs BESIDE the main plan, whose tables hold most of the memory: its share was
+        // set aside when the call started
+        const uint64_t limit = (&dst == &side_queue) ? limit_side : limit_main / (uint64_t)n_workers;
         int g0 = 0;
         while (g0 < plan.ng_total) {
             // dense columns kept: at most n_warmup (+1 so that the launch that writes d of the last
             // dense column has somewhere to put its speculative next column)
             const int Lc = (int)std::min<int64_t>((int64_t)pc->max_len, std::min<int64_t>(prm.n_warmup + 2, pc->lc_cap));
-            const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8;
+            // tables + (mapping flow) three emit-prob planes and the per-run maxima (mapping_flow.hip: pbuf)
+            const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8 + (sink ? 3 * NW * 8 + (size_t)plan.nblk8 * BLOCK * 8 : 0);
             int ngc = (int)std::min<uint64_t>(plan.ng_total - g0, std::max<uint64_t>(1, limit / std::max<size_t>(per_group, 1)));
             ngc = std::min(ngc, std::max(1, target));
             // longest read of the chunk (the order need not be by length)
@@ -626,6 +642,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                     if (!deferred) PHMM_THROW(PHMM_EINTERNAL, "warm-up ran past n_warmup");
                     const size_t slot = (size_t)g0 * W + gi;
                     deferred->push_back(plan.order[slot]);
+                    new_flags[plan.order[slot]] |= PHMM_READ_DEFERRED;
                     if (std::getenv("PHMM_TRACE"))
                         std::fprintf(stderr, "      read %u (len %d) still dense at column %d: deferred\n", plan.order[slot],
                                      hl[gi], Lc);
@@ -635,8 +652,10 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         // hand the deferred reads over NOW: their small plan runs on the side stream under the rest of this chunk
         if (!deferred_ids.empty()) {
             std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan_ids(m, reads, deferred_ids), (int64_t)prm.n_warmup + 2, false, {}});
+            // (a group of the deferred plan that does not fit the side budget waits for the main plan's tables instead)
+            const size_t side_group = ((size_t)(prm.n_warmup + 2) * 24 + 4 * 8 + (sink ? 3 * 8 : 0)) * m->N * pc->plan.W;
             std::lock_guard<std::mutex> lk(mu);
-            if (single_mode && side_on) {
+            if (single_mode && side_on && side_group <= limit_side) {
                 enqueue_plan(std::move(pc), side_queue);
                 if (!side_started) {
                     side_started = true;
@@ -654,7 +673,10 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             if (hsw[gi] < hl[gi]) {
                 // ratio mode: a forced switch with more than 400 nodes inside the ratio; fixed mode: always
                 // (top_nodes(n_active_nodes) of the last dense column)
-                if (!by_ratio || hcn[gi] > PHMM_MAX_ACTIVE_NODES) need400.push_back((uint32_t)gi);
+                if (!by_ratio || hcn[gi] > PHMM_MAX_ACTIVE_NODES) {
+                    need400.push_back((uint32_t)gi);
+                    if (by_ratio) new_flags[plan.order[(size_t)g0 * W + gi]] |= PHMM_READ_FORCED_SWITCH;
+                }
                 sparse_lanes.push_back((uint32_t)gi);
             }
         }
@@ -750,6 +772,8 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                     // it could not hold a short C <400> burst followed by B again
                     const int phase = round == 0 ? 0 : ((round & 1) ? 1 : 2);
                     HIP_CHECK(hipMemcpyAsync(wp + o_lanes, todo.data(), todo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                    if (phase == 2 && attempt == 0)
+                        for (uint32_t gi : todo) new_flags[plan.order[(size_t)g0 * W + gi]] |= PHMM_READ_WIDE_FRONTIER;
                     fa.mode = phase == 0 ? 0 : 1;
                     // C bursts grow (8, 16, ... 512 positions) so that a read whose frontier stays wide still ends
                     fa.max_steps = phase == 0 ? 6 : (phase == 2 ? (8 << std::min(round / 2 - 1, 6)) : 0);
@@ -852,9 +876,9 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     };  // run_chunk
     start_side_worker = [&]() {
         const ThreadContext ctx = capture_thread_context();
-        if (!m->wstream[1]) HIP_CHECK(hipStreamCreateWithFlags(&m->wstream[1], hipStreamNonBlocking));
+        if (!m->pool->wstream[1]) HIP_CHECK(hipStreamCreateWithFlags(&m->pool->wstream[1], hipStreamNonBlocking));
         side_thread = std::thread([&, ctx]() {
-            adopt_thread_context(ctx, m->wstream[1], 1);
+            adopt_thread_context(ctx, m->pool->wstream[1], 1);
             for (;;) {
                 Item it{};
                 {
@@ -872,7 +896,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                     if (!first_error) first_error = std::current_exception();
                 }
             }
-            (void)hipStreamSynchronize(m->wstream[1]);
+            (void)hipStreamSynchronize(m->pool->wstream[1]);
             std::lock_guard<std::mutex> lk(mu);
             side_stats = stats();
         });
@@ -922,7 +946,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             main_done = true;
         }
         cv.notify_all();
-        if (side_started) {
+        if (side_started && side_thread.joinable()) {
             side_thread.join();
             CallStats &st = stats();
             for (int k = 0; k < 4; k++) {
@@ -935,13 +959,23 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         HIP_CHECK(hipStreamSynchronize(current_stream()));  // uploads / memsets the chunks depend on
         const ThreadContext ctx = capture_thread_context();
         CallStats merged;
+        // every stream exists before the first thread does: a failing create must not unwind past joinable threads
+        for (int t = 0; t < n_threads; t++)
+            if (!m->pool->wstream[t]) HIP_CHECK(hipStreamCreateWithFlags(&m->pool->wstream[t], hipStreamNonBlocking));
         std::vector<std::thread> threads;
+        struct JoinAll {
+            std::vector<std::thread> &t;
+            ~JoinAll() {
+                for (auto &th : t)
+                    if (th.joinable()) th.join();
+            }
+        } join_all{threads};
+        threads.reserve(n_threads);
         for (int t = 0; t < n_threads; t++) {
-            if (!m->wstream[t]) HIP_CHECK(hipStreamCreateWithFlags(&m->wstream[t], hipStreamNonBlocking));
             threads.emplace_back([&, t]() {
-                adopt_thread_context(ctx, m->wstream[t], t);
+                adopt_thread_context(ctx, m->pool->wstream[t], t);
                 worker_loop();
-                (void)hipStreamSynchronize(m->wstream[t]);
+                (void)hipStreamSynchronize(m->pool->wstream[t]);
                 std::lock_guard<std::mutex> lk(mu);
                 const CallStats &ws = stats();
                 for (int k = 0; k < 4; k++) {
@@ -955,7 +989,10 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         stats() = merged;
     }
     if (first_error) std::rethrow_exception(first_error);
-    if (by_ratio) reads->warm_hint = new_hint;
+    if (by_ratio) {
+        reads->warm_hint = new_hint;
+        reads->last_flags = new_flags;
+    }
     double tot = 0.0;
     for (uint64_t r = 0; r < R; r++) tot += lf[r];
     put_doubles(out_logp, lf.data(), R);

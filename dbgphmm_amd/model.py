@@ -51,6 +51,13 @@ class ReadCollection:
     def total_bases(self) -> int:
         return int(self.offsets[-1])
 
+    def last_call_info(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(dense warm-up columns[R], PHMM_READ_* flags[R]) of the most recent adaptive-sparse call."""
+        cols = np.empty(len(self.reads), dtype=np.uint16)
+        flags = np.empty(len(self.reads), dtype=np.uint32)
+        _ffi.check(_ffi.lib().phmm_reads_last_call_info(self._h, _ptr(cols), _ptr(flags)))
+        return cols, flags
+
 
 class Mappings:
     """Mappings (src/hmmv2/hint.rs:150-152) over a ReadCollection: 3-level CSR."""

@@ -18,9 +18,10 @@
  *    phmm_last_error() returns the message (thread-local).  Nothing unwinds across
  *    the ABI.  Where the reference panics (empty read, capacity overflow) the call
  *    fails with PHMM_EINVAL / PHMM_ECAPACITY.
- *  - handles own their device memory; destroy them explicitly.  Calls on one handle
- *    are not re-entrant; the natural cut is one call per read set (all reads x all
- *    candidates), replacing the rayon `par_iter` loops of the reference.
+ *  - handles own their model / read / mapping arrays; destroy them explicitly.  The DP
+ *    workspaces belong to the device (phmm_release_workspace).  Compute calls on one
+ *    device are serialised internally; the natural cut is one call per read set (all
+ *    reads x all candidates), replacing the rayon `par_iter` loops of the reference.
  */
 #ifndef PHMM_AMD_H
 #define PHMM_AMD_H
@@ -67,8 +68,16 @@ int phmm_device_count(void);
 int phmm_set_device(int device);
 /* run subsequent work of this thread on the given hipStream_t (NULL = default stream) */
 int phmm_set_stream(void *hip_stream);
-/* upper bound (bytes) for the DP-table workspace of one call; 0 = 80% of free HBM */
+/* upper bound (bytes) for the DP-table workspace of one call; 0 = 90% of free HBM */
 int phmm_set_workspace_limit(uint64_t bytes);
+/* Workspaces (DP tables, record pools, scratch) belong to the DEVICE and are shared by every handle on it:
+ * a mapping model and a scoring model can be alive together, as in multi_dbg/posterior.rs:247-255, 609-630
+ * (the reference builds a fresh PModel per call and drops its tables on return).  They grow on demand and are
+ * kept between calls; phmm_release_workspace() returns all of it to the device (the calling thread's current
+ * device must be idle), phmm_workspace_bytes() says how much is held.  Calls that compute on one device are
+ * serialised inside the library whatever handle or thread they come from. */
+int phmm_release_workspace(void);
+uint64_t phmm_workspace_bytes(void);
 
 /* PHMMParams::new / uniform, params.rs:73-125 (arguments are LINEAR probabilities) */
 int phmm_params_new(double p_mismatch, double p_gap_open, double p_gap_ext, double p_end,
@@ -99,6 +108,15 @@ int phmm_reads_create(const uint8_t *bases, const uint64_t *offsets, uint64_t n_
 uint64_t phmm_reads_count(const phmm_reads *r);
 uint64_t phmm_reads_total_bases(const phmm_reads *r);
 void phmm_reads_destroy(phmm_reads *r);
+/* What the most recent adaptive-sparse call on these reads (phmm_generate_mappings / phmm_full_prob_reads with
+ * mappings == NULL and use_max_ratio != 0) did with each read -- for tools and parity tests that want to sample
+ * the rare code paths.  out_dense_columns[R]: the read's dense/sparse switch position = number of dense warm-up
+ * tables (forward.rs:107-137; the read length when it never switched).  out_flags[R]: PHMM_READ_* bits.
+ * Either may be NULL.  PHMM_EINVAL before the first such call. */
+#define PHMM_READ_DEFERRED 1u      /* still dense after the main plan's kept columns: redone in the all-columns plan */
+#define PHMM_READ_WIDE_FRONTIER 2u /* its frontier outgrew the one-lane-per-node class at least once (400-slot bursts) */
+#define PHMM_READ_FORCED_SWITCH 4u /* switched at n_warmup with more than 400 nodes inside the ratio (top-400 selection) */
+int phmm_reads_last_call_info(const phmm_reads *r, uint16_t *out_dense_columns, uint32_t *out_flags);
 
 /* ---- dense forward + backward + posteriors ----------------------------------
  * PHMMModel::run over a read set (src/hmmv2/freq.rs:42-46) followed by

@@ -26,3 +26,49 @@ def _finite_close(a, b, atol, floor):
     if floor is not None:
         ok |= (b < floor) & (np.isneginf(a) | (np.abs(a - b) <= 1e-3))
     return ok
+
+
+def compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6, top_k=0, ratio=30.0, edge=1e-6):
+    """Mapping lists of the GPU against the oracle's, position by position (CSR triples over the same reads).
+    Entries above e^min_logp agree in order, node and value (`tol`).  In ratio mode every entry that is not within
+    `edge` of the cut (best - ratio; rounding may put such an entry on either side) must be on BOTH lists with the
+    same value -- so the list lengths agree up to entries at the cut.  Equal probabilities may swap places (the two
+    haplotype copies of a k-mer; sparsevec's tie order is unpinned)."""
+    gpo, gnd, glp = gpu_arrays
+    opo, ond, olp = orc_arrays
+    assert gpo.shape == opo.shape
+    g = 0
+    for r in reads:
+        for i in range(len(r)):
+            a0, a1 = int(gpo[g]), int(gpo[g + 1])
+            b0, b1 = int(opo[g]), int(opo[g + 1])
+            gn, gl = gnd[a0:a1], glp[a0:a1]
+            on, ol = ond[b0:b1], olp[b0:b1]
+            # entries that matter (prob > e^min_logp) must agree in order, node and value
+            ka, kb = int((gl > min_logp).sum()), int((ol > min_logp).sum())
+            assert ka == kb, (i, gn, gl, on, ol)
+            # (nodes with equal probability -- e.g. the two haplotype copies of a k-mer -- may swap)
+            assert np.max(np.abs(gl[:ka] - ol[:kb]), initial=0.0) < tol, (i, gl, ol)
+            capped = a1 - a0 == 400 or b1 - b0 == 400
+            if capped:
+                # list capped at MAX_ACTIVE_NODES: which of the nodes that TIE with the 400th value are
+                # kept is arbitrary (sparsevec tie order is unpinned); compare strictly above the cut
+                ka = kb = int((gl > gl[-1] + 1e-9).sum())
+            assert sorted(gn[:ka].tolist()) == sorted(on[:kb].tolist()), (i, gn, on)
+            od = dict(zip(on[:kb].tolist(), ol[:kb].tolist()))
+            assert all(abs(od[n] - l) < tol for n, l in zip(gn[:ka].tolist(), gl[:ka].tolist())), (i, gn, gl, on, ol)
+            # lists are sorted descending and respect the ratio / the fixed size
+            assert np.all(np.diff(gl[np.isfinite(gl)]) <= 1e-12)
+            if top_k:
+                assert a1 - a0 == b1 - b0 <= top_k
+            elif a1 > a0:
+                assert gl[0] - gl[-1] < ratio + 1e-9
+                if not capped and b1 > b0 and np.isfinite(gl[0]):
+                    # the whole list, down to the cut: same members, same values
+                    cut = max(gl[0], ol[0]) - ratio + edge
+                    ga = {int(n): float(l) for n, l in zip(gn, gl) if l > cut}
+                    oa = {int(n): float(l) for n, l in zip(on, ol) if l > cut}
+                    assert set(ga) == set(oa), (i, sorted(set(ga) ^ set(oa)), gl, ol)
+                    assert all(abs(ga[n] - oa[n]) < max(tol, 1e-5) for n in ga), (i, gl, ol)
+                    assert abs((a1 - a0) - (b1 - b0)) <= sum(1 for l in list(gl) + list(ol) if l <= cut), (i, gl, ol)
+            g += 1

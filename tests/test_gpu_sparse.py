@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import dbgphmm_amd as D
-from helpers import finite_close, small_dbg_model
+from helpers import compare_mappings as _compare_mappings, finite_close, small_dbg_model
 
 pytestmark = pytest.mark.gpu
 TOL_LOGP = 1e-9  # BASELINE.json bar: |delta ln P(R|X)| < 1e-6 per read
@@ -192,38 +192,6 @@ def test_fixed_top_k_generate_mappings_matches_oracle(gpu_lib, oracle, cfg):
     assert abs(nf.sum() - onf.sum()) < 1e-6 * max(1.0, onf.sum())
 
 
-def _compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6, top_k=0, ratio=30.0):
-    gpo, gnd, glp = gpu_arrays
-    opo, ond, olp = orc_arrays
-    assert gpo.shape == opo.shape
-    g = 0
-    for r in reads:
-        for i in range(len(r)):
-            a0, a1 = int(gpo[g]), int(gpo[g + 1])
-            b0, b1 = int(opo[g]), int(opo[g + 1])
-            gn, gl = gnd[a0:a1], glp[a0:a1]
-            on, ol = ond[b0:b1], olp[b0:b1]
-            # entries that matter (prob > e^min_logp) must agree in order, node and value
-            ka, kb = int((gl > min_logp).sum()), int((ol > min_logp).sum())
-            assert ka == kb, (i, gn, gl, on, ol)
-            # (nodes with equal probability -- e.g. the two haplotype copies of a k-mer -- may swap)
-            assert np.max(np.abs(gl[:ka] - ol[:kb]), initial=0.0) < tol, (i, gl, ol)
-            if a1 - a0 == 400:
-                # list capped at MAX_ACTIVE_NODES: which of the nodes that TIE with the 400th value are
-                # kept is arbitrary (sparsevec tie order is unpinned); compare strictly above the cut
-                ka = kb = int((gl > gl[-1] + 1e-9).sum())
-            assert sorted(gn[:ka].tolist()) == sorted(on[:kb].tolist()), (i, gn, on)
-            od = dict(zip(on[:kb].tolist(), ol[:kb].tolist()))
-            assert all(abs(od[n] - l) < tol for n, l in zip(gn[:ka].tolist(), gl[:ka].tolist())), (i, gn, gl, on, ol)
-            # lists are sorted descending and respect the ratio / the fixed size
-            assert np.all(np.diff(gl[np.isfinite(gl)]) <= 1e-12)
-            if top_k:
-                assert a1 - a0 == b1 - b0 <= top_k
-            elif a1 > a0:
-                assert gl[0] - gl[-1] < ratio + 1e-9
-            g += 1
-
-
 def test_generate_mappings_toy_kat(gpu_lib):
     """multi_dbg/posterior/test.rs:544-576 (hint_for_toy): best node per base on toy::repeat()."""
     import json, os
@@ -387,6 +355,42 @@ def test_mappings_map_nodes_matches_oracle(gpu_lib, oracle):
             assert sorted(got[1][s0:s1].tolist()) == sorted(exp[1][s0:s1].tolist())
     with pytest.raises(D.PhmmError):
         gmp.map_nodes(gm, np.arange(N + 1), np.full(N, N + 7))
+
+
+def test_mappings_map_nodes_wide_fan_out(gpu_lib, oracle):
+    """A node map with fan-out 12: the full first lists of a read (400 entries) have 4 800 images, more distinct
+    ones than the LDS table of one pass holds.  The reference merges any number of images and keeps the 400 best
+    (hint.rs:65-86); so does the kernel (key classes in several passes) -- no capacity error, no spinning probe."""
+    arrays, sg = small_dbg_model(4000, 12, 0.01, seed=11)
+    N = arrays.n_nodes
+    rng = np.random.default_rng(3)
+    reads = [b"ACGTACGTAC", b"TTGACA"]
+    # synthetic lists: 400 / 37 / 0 / 400 ... distinct nodes per position with descending probabilities
+    sizes = [400, 37, 0, 400, 1, 400, 250, 400, 64, 400, 400, 3, 400, 128, 399, 400]
+    pos_off, nodes, logp = [0], [], []
+    for sz in sizes:
+        nodes.extend(rng.choice(N, sz, replace=False).tolist())
+        logp.extend(np.sort(rng.uniform(-30.0, 0.0, sz))[::-1].tolist())
+        pos_off.append(len(nodes))
+    mp = (np.array(pos_off, dtype=np.uint64), np.array(nodes, dtype=np.uint32), np.array(logp))
+    gm = D.PHMMModel(arrays)
+    rc = D.ReadCollection(reads)
+    gmp = D.Mappings.from_arrays(rc, *mp)
+    assert N > 4500
+    fan = 12
+    mo = np.arange(N + 1, dtype=np.int64) * fan
+    mn = ((np.arange(N)[:, None] * 7 + np.arange(fan)[None, :] * 509) % N).reshape(-1)
+    got = gmp.map_nodes(gm, mo, mn).arrays()
+    exp = oracle.map_nodes(mp, mo, mn)
+    assert np.array_equal(got[0], exp[0]) and np.diff(got[0].astype(np.int64)).max() == 400
+    for i in range(len(exp[0]) - 1):
+        s0, s1 = int(exp[0][i]), int(exp[0][i + 1])
+        assert np.max(np.abs(got[2][s0:s1] - exp[2][s0:s1]), initial=0.0) < 1e-9, i
+        if s1 - s0 < 400:
+            assert sorted(got[1][s0:s1].tolist()) == sorted(exp[1][s0:s1].tolist()), i
+        else:  # capped: the nodes tied at the cut are an arbitrary subset
+            above = exp[2][s0:s1] > exp[2][s1 - 1] + 1e-9
+            assert set(exp[1][s0:s1][above].tolist()) <= set(got[1][s0:s1].tolist()), i
 
 
 def test_edge_cases_match_oracle(gpu_lib, oracle):
