@@ -88,3 +88,44 @@ def test_dbg_roundtrip_matches_builder(tmp_path, seed, k):
     ta = sorted(zip(a.edge_src.tolist(), a.edge_dst.tolist(), a.trans_logp.tolist()))
     tb = sorted(zip(b.edge_src.tolist(), b.edge_dst.tolist(), b.trans_logp.tolist()))
     assert ta == tb
+
+
+def test_readme_dbg_text_is_toy_repeat():
+    """The DBG text the reference documents (README.md:176-190) is toy::repeat() (multi_dbg/toy.rs:260-303): read
+    back it gives the same node-centric graph, node ids included (tests/test_gpu_sparse.py runs the toy-hint KAT
+    of multi_dbg/posterior/test.rs:544-576 on the graph read from this file)."""
+    import os
+    dbg = F.read_dbg(os.path.join(os.path.dirname(__file__), "golden", "toy_repeat_readme.dbg"))
+    assert dbg.k == 4 and dbg.n_edges_full == 15 and dbg.km1mers == [b"nnn", b"CAG"]
+    sg, k = D.toy_repeat()
+    _same_graph(dbg.to_seq_graph(), sg)
+
+
+@pytest.mark.parametrize("name", ["circular", "linear", "intersection", "selfloop", "repeat"])
+def test_toy_dbg_dump_load(tmp_path, name):
+    """multi_dbg/output.rs:846-905 (dumpload, dbg_gz_compressed) on the five toy graphs: string -> graph -> string
+    is stable, the k-mer copy-number map survives, plain and gzip files agree."""
+    import json, os
+    toy = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "toy_dbgs.json")))[name]
+    kmers = [x.encode() for x in toy["kmers"]]
+    dbg = F.dbg_from_seq_graph_kmers(kmers, toy["copy_nums"], toy["k"])
+    import io
+    buf = io.StringIO()
+    F.write_dbg(buf, dbg)
+    s = buf.getvalue()
+    back = F.read_dbg(s, is_text=True)
+    buf1 = io.StringIO()
+    F.write_dbg(buf1, back)
+    assert buf1.getvalue() == s
+    kmer_map = lambda d: {e[2]: e[3] for e in d.edges}  # to_kmer_copy_num_map
+    assert kmer_map(back) == dict(zip(kmers, toy["copy_nums"]))
+    for fn in ("hoge.dbg", "repeat.dbg.gz"):
+        F.write_dbg(str(tmp_path / fn), dbg)
+        assert kmer_map(F.read_dbg(str(tmp_path / fn))) == kmer_map(dbg)
+    # the PHMM topology: one node per k-mer, no edge through the all-n terminal, emission = last base
+    sg = back.to_seq_graph()
+    assert sg.base.tolist() == [km[-1] for km in kmers] and sg.copy_num.tolist() == toy["copy_nums"]
+    for a, b in zip(sg.edge_src.tolist(), sg.edge_dst.tolist()):
+        assert kmers[a][1:] == kmers[b][:-1] and kmers[a][1:] != b"n" * (toy["k"] - 1)
+    if name == "repeat":
+        _same_graph(sg, D.toy_repeat()[0])

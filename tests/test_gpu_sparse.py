@@ -204,6 +204,31 @@ def test_generate_mappings_toy_kat(gpu_lib):
         assert [mp.nodes(0, i)[0] for i in range(len(read))] == best
 
 
+def test_generate_mappings_toy_kat_from_the_documented_dbg_file(gpu_lib):
+    """The same KAT on the graph read from the DBG text the reference documents (README.md:176-190)."""
+    import json, os
+    from dbgphmm_amd import formats as F
+    here = os.path.dirname(__file__)
+    kat = json.load(open(os.path.join(here, "golden", "kat_hmmv2.json")))["toy_repeat_hints"]
+    dbg = F.read_dbg(os.path.join(here, "golden", "toy_repeat_readme.dbg"))
+    gm = D.PHMMModel(dbg.to_seq_graph().to_non_zero_phmm(D.PHMMParams.uniform(kat["p"]).with_(n_warmup=dbg.k)))
+    for read, best in kat["reads"].items():
+        mp, nf = gm.generate_mappings(D.ReadCollection([read.encode()]), None, True)
+        assert [mp.nodes(0, i)[0] for i in range(len(read))] == best
+
+
+@pytest.mark.parametrize("case", ["case1", "case2"])
+def test_map_nodes_kat(gpu_lib, case):
+    """hint.rs:233-263 (mapping_node_convert) through the device kernel."""
+    from test_oracle_kat import _map_nodes_case
+    (po, nd, lp), mo, mn, exp = _map_nodes_case(case)
+    gm = D.PHMMModel(D.mock_linear().to_phmm(D.PHMMParams.uniform(0.01)))  # any model with >= 6 nodes
+    rc = D.ReadCollection([b"AC"])
+    got = D.Mappings.from_arrays(rc, po, nd, lp).map_nodes(gm, mo, mn).arrays()
+    assert got[1].tolist() == sum(exp["nodes"], [])
+    assert np.max(np.abs(np.exp(got[2]) - np.array(sum(exp["probs"], [])))) < 1e-15
+
+
 @pytest.mark.parametrize("cfg", [(300, 12, 0.001, 9, 30), (600, 16, 0.001, 3, 40), (600, 12, 0.01, 3, 24), (900, 16, 0.003, 21, 70)])
 def test_generate_mappings_matches_oracle(gpu_lib, oracle, cfg):
     """generate_mappings(reads, None, true) = run_sparse_adaptive + to_mapping_by_score_ratio

@@ -171,3 +171,27 @@ def test_dense_vs_sparse_property(oracle):
     lf, lb, _ = om.run_dense_reads(reads)
     assert abs(p0 - lf.sum()) < 1e-4 and abs(p1 - lf.sum()) < 1e-4
     assert abs(lf.sum() - lb.sum()) < 0.01 * len(reads)
+
+
+def _map_nodes_case(case):
+    k = KAT["map_nodes"]
+    po = np.array([0, 2, 4], dtype=np.uint64)
+    nd = np.array(sum(k["nodes"], []), dtype=np.uint32)
+    lp = np.log(np.array(sum(k["probs"], [])))
+    n_old = 5
+    if case == "case1":  # v -> [v+1]
+        mo, mn = np.arange(n_old + 1), np.arange(1, n_old + 1)
+    else:                # v -> [v, v+1]
+        mo, mn = np.arange(n_old + 1) * 2, np.stack([np.arange(n_old), np.arange(1, n_old + 1)], axis=1).reshape(-1)
+    return (po, nd, lp), mo, mn, k[case]
+
+
+@pytest.mark.parametrize("case", ["case1", "case2"])
+def test_map_nodes_kat(oracle, case):  # hint.rs:233-263
+    mp, mo, mn, exp = _map_nodes_case(case)
+    po, nd, lp = oracle.map_nodes(mp, mo, mn)
+    assert po.tolist() == [0, len(exp["nodes"][0]), len(exp["nodes"][0]) + len(exp["nodes"][1])]
+    assert nd.tolist() == sum(exp["nodes"], [])
+    if case == "case1":
+        assert np.array_equal(lp, mp[2])  # the reference asserts Mapping equality (hint.rs:262)
+    assert np.max(np.abs(np.exp(lp) - np.array(sum(exp["probs"], [])))) < 1e-15
