@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const in
     constexpr bool DMA_ = DMA && W == 64;
     // per wave: DMA_DEPTH slots of [m row 512 B][i row 512 B]
     __shared__ double ring[DMA_ ? (BLOCK / 64) * DMA_DEPTH * 128 : 1];
-    const int g = blockIdx.y;
+    const int g = blockIdx.y + a.g_off;
     const int lb = xcd_block(blockIdx.x, a.nblk8);
     constexpr int ROWS = BLOCK / W;
     const int r = threadIdx.x % W;
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
     __shared__ double lds[(BLOCK / 64) * 64];
     constexpr bool DMA_ = DMA && W == 64;
     __shared__ double ring[DMA_ ? (BLOCK / 64) * BDMA_DEPTH * BDMA_SLOT : 1];
-    const int g = blockIdx.y;
+    const int g = blockIdx.y + a.g_off;
     const int lb = xcd_block(blockIdx.x, a.nblk8);
     constexpr int ROWS = BLOCK / W;
     const int r = threadIdx.x % W;
@@ -913,33 +913,100 @@ struct Timer {
     }
 };
 
+// one forward / backward column for the read groups [g_off, g_off + g_cnt) on stream s (g_cnt < 0: all, current stream)
+template <int W> static void launch_fwd_one(const DenseArgs &a0, int pos, int g_off = 0, int g_cnt = -1, hipStream_t s = nullptr) {
+    static const bool dma = std::getenv("PHMM_NO_DMA") == nullptr;
+    DenseArgs a = a0;
+    a.g_off = g_off;
+    if (g_cnt < 0) {
+        g_cnt = a.ng;
+        s = current_stream();
+    }
+    if (W == 64 && dma && a.npt % DMA_DEPTH == 0)
+        hipLaunchKernelGGL((fwd_step<W, true>), dim3(a.nblk8, g_cnt), dim3(BLOCK), 0, s, a, pos);
+    else
+        hipLaunchKernelGGL((fwd_step<W, false>), dim3(a.nblk8, g_cnt), dim3(BLOCK), 0, s, a, pos);
+}
+template <int W> static void launch_bwd_one(const DenseArgs &a0, int pos, int g_off = 0, int g_cnt = -1, hipStream_t s = nullptr) {
+    static const bool dma = std::getenv("PHMM_BWD_DMA") != nullptr;
+    DenseArgs a = a0;
+    a.g_off = g_off;
+    if (g_cnt < 0) {
+        g_cnt = a.ng;
+        s = current_stream();
+    }
+    if (W == 64 && dma)
+        hipLaunchKernelGGL((bwd_step<W, true>), dim3(a.nblk8, g_cnt), dim3(BLOCK), 0, s, a, pos);
+    else
+        hipLaunchKernelGGL((bwd_step<W, false>), dim3(a.nblk8, g_cnt), dim3(BLOCK), 0, s, a, pos);
+}
+// Small graphs (cfg2: N = 1e4): one column of one chunk is a launch of a few hundred blocks that lives ~30 us, most of
+// it the dependent-load chain of a wave (column header -> window rebuild -> rows -> reductions), with the machine
+// neither full nor streaming.  Read groups are independent from the first forward column to the last backward one, so
+// the chunk's groups are dealt to up to 4 streams whose launch sequences overlap: while one is in its latency
+// phases another streams.  Large launches (cfg3) fill the chip on their own and stay on one stream.
+static int dense_stream_count(const DenseArgs &a) {
+    static const int forced = std::getenv("PHMM_DENSE_STREAMS") ? std::atoi(std::getenv("PHMM_DENSE_STREAMS")) : 0;
+    int k = forced;
+    if (k <= 0) {
+        const long blocks = (long)a.nblk8 * a.ng;
+        k = blocks >= 4096 ? 1 : (blocks >= 1536 ? 2 : 3);
+    }
+    return std::max(1, std::min(std::min(k, MAX_WORKERS), a.ng));
+}
 template <int W>
-void launch_chunk(const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
+void launch_chunk(phmm_model *m, const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
     hipStream_t s = current_stream();
-    dim3 grid(a.nblk8, a.ng), blk(BLOCK);
+    dim3 blk(BLOCK);
     Timer tf(timing), tb(timing);
+    const int K = dense_stream_count(a);
+    hipStream_t ks[MAX_WORKERS] = {s, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[MAX_WORKERS] = {};
+    if (K > 1) {
+        HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int k = 1; k < K; k++) {
+            if (!m->pool->wstream[k]) HIP_CHECK(hipStreamCreateWithFlags(&m->pool->wstream[k], hipStreamNonBlocking));
+            ks[k] = m->pool->wstream[k];
+            HIP_CHECK(hipEventCreateWithFlags(&join[k], hipEventDisableTiming));
+        }
+    }
+    auto g_lo = [&](int k) { return (int)((long)a.ng * k / K); };
+    auto fan_out = [&] {
+        if (K == 1) return;
+        HIP_CHECK(hipEventRecord(fork, s));
+        for (int k = 1; k < K; k++) HIP_CHECK(hipStreamWaitEvent(ks[k], fork, 0));
+    };
+    auto fan_in = [&] {
+        for (int k = 1; k < K; k++) {
+            HIP_CHECK(hipEventRecord(join[k], ks[k]));
+            HIP_CHECK(hipStreamWaitEvent(s, join[k], 0));
+        }
+    };
     tf.start();
-    for (int pos = 0; pos <= a.Lc; pos++) hipLaunchKernelGGL((fwd_step<W, false>), grid, blk, 0, s, a, pos);
+    fan_out();
+    for (int pos = 0; pos <= a.Lc; pos++)
+        for (int k = 0; k < K; k++) launch_fwd_one<W>(a, pos, g_lo(k), g_lo(k + 1) - g_lo(k), ks[k]);  // (W = 64: the LDS-DMA variant)
+    fan_in();
     st.ms[0] += tf.stop();
     st.launches[0] += (uint64_t)a.Lc + 1;
     hipLaunchKernelGGL(fwd_finish<W>, dim3(a.ng, a.eall ? a.Lc : 1), blk, 0, s, a);
     if (do_bwd) {
         tb.start();
-        for (int pos = a.Lc - 1; pos >= 0; pos--) hipLaunchKernelGGL((bwd_step<W, false>), grid, blk, 0, s, a, pos);
+        fan_out();
+        for (int pos = a.Lc - 1; pos >= 0; pos--)
+            for (int k = 0; k < K; k++) launch_bwd_one<W>(a, pos, g_lo(k), g_lo(k + 1) - g_lo(k), ks[k]);
+        fan_in();
         st.ms[1] += tb.stop();
         st.launches[1] += (uint64_t)a.Lc;
         hipLaunchKernelGGL(bwd_finish<W>, dim3(a.ng), blk, 0, s, a);
     }
-    HIP_CHECK(hipGetLastError());
+    const hipError_t le = hipGetLastError();
+    if (fork) (void)hipEventDestroy(fork);
+    for (int k = 1; k < K; k++)
+        if (join[k]) (void)hipEventDestroy(join[k]);
+    HIP_CHECK(le);
 }
 
-template <int W> static void launch_fwd_one(const DenseArgs &a, int pos) {
-    static const bool dma = std::getenv("PHMM_NO_DMA") == nullptr;
-    if (W == 64 && dma && a.npt % DMA_DEPTH == 0)
-        hipLaunchKernelGGL((fwd_step<W, true>), dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
-    else
-        hipLaunchKernelGGL((fwd_step<W, false>), dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
-}
 template <int W> static void launch_fwd_fin(const DenseArgs &a) {
     hipLaunchKernelGGL(fwd_finish<W>, dim3(a.ng, a.eall ? a.Lc : 1), dim3(BLOCK), 0, current_stream(), a);
 }
@@ -958,15 +1025,6 @@ void launch_fwd_step(int W, const DenseArgs &a, int pos) {
 #define CALL_(w) launch_fwd_one<w>(a, pos)
     PHMM_W_SWITCH(W, CALL_)
 #undef CALL_
-}
-template <int W> static void launch_bwd_one(const DenseArgs &a, int pos) {
-    // The LDS-DMA variant of the backward (5 planes per row, 3 requests) measured 6 % SLOWER than the register
-    // ring on cfg3 (6.35 vs 5.96 ms per launch): opt-in only (PHMM_BWD_DMA=1), kept for the next round.
-    static const bool dma = std::getenv("PHMM_BWD_DMA") != nullptr;
-    if (W == 64 && dma)
-        hipLaunchKernelGGL((bwd_step<W, true>), dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
-    else
-        hipLaunchKernelGGL((bwd_step<W, false>), dim3(a.nblk8, a.ng), dim3(BLOCK), 0, current_stream(), a, pos);
 }
 void launch_bwd_step(int W, const DenseArgs &a, int pos) {
 #define CALL_(w) launch_bwd_one<w>(a, pos)
@@ -988,15 +1046,15 @@ void launch_fwd_finish(int W, const DenseArgs &a) {
 #undef CALL_
 }
 
-void launch_chunk_w(int W, const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
+void launch_chunk_w(phmm_model *m, int W, const DenseArgs &a, bool do_bwd, CallStats &st, bool timing) {
     switch (W) {
-    case 1: launch_chunk<1>(a, do_bwd, st, timing); break;
-    case 2: launch_chunk<2>(a, do_bwd, st, timing); break;
-    case 4: launch_chunk<4>(a, do_bwd, st, timing); break;
-    case 8: launch_chunk<8>(a, do_bwd, st, timing); break;
-    case 16: launch_chunk<16>(a, do_bwd, st, timing); break;
-    case 32: launch_chunk<32>(a, do_bwd, st, timing); break;
-    case 64: launch_chunk<64>(a, do_bwd, st, timing); break;
+    case 1: launch_chunk<1>(m, a, do_bwd, st, timing); break;
+    case 2: launch_chunk<2>(m, a, do_bwd, st, timing); break;
+    case 4: launch_chunk<4>(m, a, do_bwd, st, timing); break;
+    case 8: launch_chunk<8>(m, a, do_bwd, st, timing); break;
+    case 16: launch_chunk<16>(m, a, do_bwd, st, timing); break;
+    case 32: launch_chunk<32>(m, a, do_bwd, st, timing); break;
+    case 64: launch_chunk<64>(m, a, do_bwd, st, timing); break;
     default: PHMM_THROW(PHMM_EINTERNAL, "bad read-group width");
     }
 }
@@ -1050,6 +1108,11 @@ Plan make_plan_ids(const phmm_model *m, const phmm_reads *reads, const std::vect
         return reads->off[x + 1] - reads->off[x] > reads->off[y + 1] - reads->off[y];
     });
     p.W = forced_w > 0 ? forced_w : choose_width(R);
+    // (tuning knobs: PHMM_DENSE_W forces the read-group width, PHMM_DENSE_NPT the run length)
+    if (const char *e = std::getenv("PHMM_DENSE_W")) {
+        const int w = std::atoi(e);
+        if (w == 1 || w == 2 || w == 4 || w == 8 || w == 16 || w == 32 || w == 64) p.W = w;
+    }
     p.ng_total = (int)((R + p.W - 1) / p.W);
     const int rows = BLOCK / p.W;
     // run length (consecutive nodes walked by one row of W lanes): as long as the launch still
@@ -1059,6 +1122,7 @@ Plan make_plan_ids(const phmm_model *m, const phmm_reads *reads, const std::vect
     const double lanes_total = (double)m->N * (double)(p.ng_total * p.W);
     while (npt < 64 && lanes_total / (npt * 2) >= 524288.0) npt *= 2;
     while ((int64_t)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows)) > 4096 && npt < 64) npt *= 2;
+    if (const char *e = std::getenv("PHMM_DENSE_NPT")) npt = std::max(2, std::min(256, std::atoi(e) & ~1));
     p.npt = npt;
     p.nblk = (int)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows));
     p.nblk8 = (p.nblk + 7) / 8 * 8;
@@ -1243,7 +1307,7 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
         HIP_CHECK(hipMemcpyAsync((void *)a.logib, hib.data(), hib.size() * sizeof(double), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipStreamSynchronize(s));  // staging vectors may now die; timed region excludes upload
 
-        launch_chunk_w(W, a, want_b || want_freq, st, timing_enabled());
+        launch_chunk_w(m, W, a, want_b || want_freq, st, timing_enabled());
         st.cells[0] += cells;
         if (want_b || want_freq) st.cells[1] += cells;
 
@@ -1312,7 +1376,7 @@ void run_dense_impl(phmm_model *m, const uint8_t *bases, const uint64_t *off, ui
                 HIP_CHECK(hipMemcpyAsync((void *)a.len, hl2.data(), hl2.size() * sizeof(int), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipMemcpyAsync((void *)a.logib, hib.data(), hib.size() * sizeof(double), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                launch_chunk_w(W, a, true, st, false);
+                launch_chunk_w(m, W, a, true, st, false);
             }
             trace("dense: reads outside the scaled range");
         }

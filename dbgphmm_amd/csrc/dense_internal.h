@@ -13,6 +13,7 @@ static constexpr int BLOCK = 256;
 
 struct DenseArgs {
     int N, ng, Lc, nblk, npt;
+    int g_off;  // first read group of this launch (fwd_step / bwd_step: grid.y counts from here; 0 = all groups)
     // model
     const NodeRec *nodes;
     const uint8_t *emis;

@@ -94,16 +94,20 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         return p;
     };
     // to_mapping_by_score_ratio of the values on the lanes (has: lane carries an entry; slot: its record
-    // slot, the tie order): kept = val > 0 and within the ratio of the best, sorted descending
+    // slot): kept = val > 0 and within the ratio of the best, sorted descending, equal values by node id
     auto emit = [&](uint64_t pos_index, bool has, uint32_t nid, double val, int slot) -> bool {
+        (void)slot;
         const double v = has ? val : 0.0;
         const double p0v = wave_max(v);
         const bool keep = has && v > 0.0 && v > p0v * a.ratio_lin;
         const unsigned long long km = __ballot(keep);
         const int k = __popcll(km);
+        // ordered by the value the list holds (the log) and equal logs by node id: the same list whatever lanes the
+        // read's nodes sit on and however its reads were grouped (see emit_mapping, mapping_flow.hip)
+        const double lv = keep ? log(v) : 0.0;
         int rank = 0;
         unsigned long long mm = km;
-        const long long vb = __double_as_longlong(v);
+        const long long vb = __double_as_longlong(lv);
         while (mm) {
             // (l is wave-uniform: scalar lane reads instead of ds_bpermute round trips)
             const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
@@ -111,8 +115,8 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
             const int ulo = __builtin_amdgcn_readlane((int)(vb & 0xffffffffll), l);
             const int uhi = __builtin_amdgcn_readlane((int)(vb >> 32), l);
             const double u = __longlong_as_double(((long long)uhi << 32) | (long long)(unsigned int)ulo);
-            const int us = __builtin_amdgcn_readlane(slot, l);
-            rank += (u > v) || (u == v && us < slot);
+            const uint32_t un = (uint32_t)__builtin_amdgcn_readlane((int)nid, l);
+            rank += (u > lv) || (u == lv && un < nid);
         }
         const uint64_t idb = (uint64_t)((k + 1) & ~1) * 4;
         const uint64_t bytes = (8 + idb + (uint64_t)k * 8 + 15) & ~15ull;
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         }
         if (keep) {
             ((uint32_t *)(rec + 8))[rank] = nid;
-            ((double *)(rec + 8 + idb))[rank] = log(v);
+            ((double *)(rec + 8 + idb))[rank] = lv;
         }
         return true;
     };

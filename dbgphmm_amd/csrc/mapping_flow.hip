@@ -57,24 +57,38 @@ template <int CAP> __device__ bool load_record(const RecPool &p, uint64_t pos_in
 }
 
 // to_mapping_by_score_ratio for one position (table.rs:134-149, 163-169): sort val desc
-// (stable in slot order, or by node id when by_node), keep while ln p0 - ln p < ratio,
+// (equal values by node id -- every caller passes by_node: a list must not depend on the slot order its read's
+// nodes happened to have; stable in slot order otherwise), keep while ln p0 - ln p < ratio,
 // write [n][pad] ids logp.  Returns false if the pool is full.
 template <int CAP>
-__device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32_t *ids, const double *val, int n,
+__device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32_t *ids, double *val, int n,
                              double ratio_lin, bool by_node, uint16_t *order, int topk = 0, long long prealloc = -1) {
     // Only the entries that stay need a rank: with the ratio rule they are the largest ones, so their rank among
     // all entries is their rank among themselves (a column next to the dense/sparse switch has up to 400
     // entries of which a handful stay).
+    // The list is ordered by the values it holds -- the LOGS -- and equal logs by node id: two nodes whose linear
+    // values differ in the last bit (the two haplotype copies of a k-mer) usually share one log value, and which of
+    // the two is a bit larger depends on the order of additions, i.e. on how the reads were grouped.  Ordered this
+    // way a list is the same whatever the grouping.  val[] is overwritten: log value of an entry that stays, NaN
+    // (never ranked, compares false) otherwise.
     double thr = -1.0;  // topk: every entry is ranked
     if (topk <= 0) {
         double mx = 0.0;
         for (int j = threadIdx.x; j < n; j += 64) mx = fmax(mx, val[j]);
         thr = wave_max(mx) * ratio_lin;
     }
+    __syncthreads();
     int c = 0;
     for (int j = threadIdx.x; j < n; j += 64) {
         const double v = val[j];
-        if (topk <= 0 && !(v > 0.0 && v > thr)) continue;
+        const bool stay = topk > 0 || (v > 0.0 && v > thr);
+        val[j] = stay ? (v > 0.0 ? log(v) : -INFINITY) : __longlong_as_double(0x7ff8000000000000ll);
+        c += stay ? 1 : 0;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const double v = val[j];
+        if (v != v) continue;
         const uint32_t id = ids[j];
         int rank = 0;
         for (int q0 = 0; q0 < n; q0 += 8) {  // (eight LDS reads in flight)
@@ -91,7 +105,6 @@ __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32
                 rank += (q0 + k < n) && ((u[k] > v) || (u[k] == v && (by_node ? ui[k] < id : (int)ui[k] < j)));
         }
         order[rank] = (uint16_t)j;
-        c++;
     }
     __syncthreads();
     int keep = 0;
@@ -113,7 +126,7 @@ __device__ bool emit_mapping(const RecPool &mp, uint64_t pos_index, const uint32
     for (int j = threadIdx.x; j < keep; j += 64) {
         const int s = order[j];
         oid[j] = ids[s];
-        olp[j] = val[s] > 0.0 ? log(val[s]) : -INFINITY;
+        olp[j] = val[s];
     }
     __syncthreads();
     return true;
@@ -151,7 +164,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             const double w = ok ? exp((double)fr.E * SP_LN2 - logP) * lp.p_end : 0.0;
             for (int j = lane; j < fr.n; j += 64) val[j] = w * (fr.m[j] + fr.i[j] + fr.d[j]);
             wave_sync();
-            if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, false, order, a.topk))
+            if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(len - 1), fr.id, val, fr.n, a.ratio_lin, true, order, a.topk))
                 err |= SP_ERR_POOL;
         }
     } else {
@@ -214,7 +227,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             val[j] = bs >= 0 ? w * (fr.m[j] * cur.m[bs] + fr.i[j] * cur.i[bs] + fr.d[j] * cur.d[bs]) : 0.0;
         }
         wave_sync();
-        if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, false, order, a.topk))
+        if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, true, order, a.topk))
             err |= SP_ERR_POOL;
     }
     if (a.list_off) {

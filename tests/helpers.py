@@ -28,11 +28,12 @@ def _finite_close(a, b, atol, floor):
     return ok
 
 
-def compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6, top_k=0, ratio=30.0, edge=1e-6):
+def compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6, top_k=0, ratio=30.0, edge=1e-6, deep=True):
     """Mapping lists of the GPU against the oracle's, position by position (CSR triples over the same reads).
     Entries above e^min_logp agree in order, node and value (`tol`).  In ratio mode every entry that is not within
     `edge` of the cut (best - ratio; rounding may put such an entry on either side) must be on BOTH lists with the
-    same value -- so the list lengths agree up to entries at the cut.  Equal probabilities may swap places (the two
+    same value -- so the list lengths agree up to entries at the cut (deep = False leaves that out: where the 400-slot
+    vector overflows, the unpinned regime of DESIGN.md section 2, the two restatements drop different tails).  Equal probabilities may swap places (the two
     haplotype copies of a k-mer; sparsevec's tie order is unpinned)."""
     gpo, gnd, glp = gpu_arrays
     opo, ond, olp = orc_arrays
@@ -63,7 +64,7 @@ def compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6, to
                 assert a1 - a0 == b1 - b0 <= top_k
             elif a1 > a0:
                 assert gl[0] - gl[-1] < ratio + 1e-9
-                if not capped and b1 > b0 and np.isfinite(gl[0]):
+                if deep and not capped and b1 > b0 and np.isfinite(gl[0]):
                     # the whole list, down to the cut: same members, same values
                     cut = max(gl[0], ol[0]) - ratio + edge
                     ga = {int(n): float(l) for n, l in zip(gn, gl) if l > cut}
@@ -72,3 +73,29 @@ def compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6, to
                     assert all(abs(ga[n] - oa[n]) < max(tol, 1e-5) for n in ga), (i, gl, ol)
                     assert abs((a1 - a0) - (b1 - b0)) <= sum(1 for l in list(gl) + list(ol) if l <= cut), (i, gl, ol)
             g += 1
+
+
+def same_mappings(a, b, near=1e-9):
+    """Two mapping CSR triples made by the GPU path for the same reads (another grouping of the reads, another model
+    handle, another chunking): offsets and values bit-equal; nodes equal except that entries of one list whose values
+    are within `near` of each other (the two haplotype copies of a k-mer: their linear values may differ in the last
+    bit, and which of the two gets the larger one depends on the order of additions) may trade places."""
+    po1, nd1, lp1 = a
+    po2, nd2, lp2 = b
+    if not (np.array_equal(po1, po2) and np.array_equal(lp1, lp2)):
+        return False
+    bad = np.flatnonzero(nd1 != nd2)
+    if bad.size == 0:
+        return True
+    # the differing entries of each list must be a permutation among near-equal values
+    owner = np.searchsorted(po1, bad, side="right") - 1
+    for p in np.unique(owner):
+        ix = bad[owner == p]
+        if sorted(nd1[ix].tolist()) != sorted(nd2[ix].tolist()):
+            return False
+        # every swapped entry sits in a run of near-equal values that covers its partner
+        for lo in ix:
+            partner = ix[nd2[ix] == nd1[lo]]
+            if partner.size != 1 or abs(float(lp1[lo]) - float(lp1[partner[0]])) > near:
+                return False
+    return True
