@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphmm_amd.so")
+LIB_PATH = os.environ.get("PHMM_AMD_LIB") or os.path.join(_HERE, "libphmm_amd.so")  # (PHMM_AMD_LIB: a variant build, dev only)
 CSRC = os.path.join(_HERE, "csrc")
 
 PHMM_OK, PHMM_EINVAL, PHMM_ENODEVICE, PHMM_ENOMEM, PHMM_ECAPACITY, PHMM_EINTERNAL = 0, -1, -2, -3, -4, -5

@@ -66,9 +66,20 @@ uint64_t table_budget(const DevicePool &pool, uint64_t reserve) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)16 << 30;
     double frac = 0.9;
-    if (const char *e = std::getenv("PHMM_MEM_FRACTION")) frac = std::min(0.95, std::max(0.1, std::atof(e)));
+    if (const char *e = std::getenv("PHMM_MEM_FRACTION")) frac = std::min(0.97, std::max(0.1, std::atof(e)));
     const double b = frac * (double)(fr + pool.owned_table_bytes()) - (double)reserve;
     return (uint64_t)std::max(b, 64.0 * 1024 * 1024);
+}
+// The adaptive flow plans ALL of its memory (tables, emit-prob planes, record pools, control arrays): everything the
+// pool already holds is reusable by it, so the plan starts from PHMM_MEM_FRACTION (0.95 here: nothing else is left to
+// grow beside the plan) of free + pool-owned bytes.
+uint64_t planned_budget(const DevicePool &pool) {
+    if (g_ws_limit) return g_ws_limit;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)16 << 30;
+    double frac = 0.95;
+    if (const char *e = std::getenv("PHMM_MEM_FRACTION")) frac = std::min(0.97, std::max(0.1, std::atof(e)));
+    return (uint64_t)(frac * (double)(fr + pool.owned_bytes()));
 }
 
 // ---------------------------------------------------------------- per-device workspace pool

@@ -751,8 +751,12 @@ __global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const in
                 }
             }
             if (a.want_freq) {
+                // Fire-and-forget hardware f64 add (no value returned, nothing to wait for): a plain `+=` is a
+                // load -> add -> store chain that put one memory round trip into EVERY row of the run (vmcnt is in
+                // order), which is what bounded this kernel on small graphs.  One row of one launch owns the
+                // address and launches are ordered, so the sum keeps its fixed order.
                 const double tot = lanes_sum<W>(contrib);
-                if (r == 0) a.accg[(size_t)g * a.N + v] += tot;
+                if (r == 0) (void)unsafeAtomicAdd(&a.accg[(size_t)g * a.N + v], tot);
             }
           }
         }
@@ -1118,7 +1122,8 @@ Plan make_plan_ids(const phmm_model *m, const phmm_reads *reads, const std::vect
     // run length (consecutive nodes walked by one row of W lanes): as long as the launch still
     // has >= ~8192 waves (the window fill at a run start costs 12 loads, a node on the run 2),
     // and long enough that a column has <= ~4096 per-block partials
-    int npt = 4;
+    // (the floor of 8: measured on cfg2 -- N = 1e4, 200 reads -- runs of 4 spend their time rebuilding windows)
+    int npt = 8;
     const double lanes_total = (double)m->N * (double)(p.ng_total * p.W);
     while (npt < 64 && lanes_total / (npt * 2) >= 524288.0) npt *= 2;
     while ((int64_t)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows)) > 4096 && npt < 64) npt *= 2;

@@ -730,9 +730,12 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
                  o_hand = carve(sizeof(BHandoff) * (size_t)lanes), o_eoff = carve(sizeof(unsigned long long) * 2 * (size_t)lanes);
     ctl.reserve(cb);
     char *cp = (char *)ctl.p;
-    // Pa (two buffers, by position parity), Pb and the per-run maxima of Pa
+    // Pa (two buffers, by position parity), the per-run maxima of Pa, and Pb -- the plane of merged index `len`, which
+    // only a read that ends inside the dense columns writes (none on a HiFi read set: no third plane then)
     const size_t prun_n = (size_t)mc.ngc * mc.a.nblk8 * BLOCK;
-    pbuf.reserve((3 * (size_t)mc.ngc * NW + prun_n) * sizeof(double));
+    bool need_pb = false;
+    for (int gi = 0; gi < lanes; gi++) need_pb |= hb[gi] >= 0 && !(hb[gi] & (1 << 30));
+    pbuf.reserve(((need_pb ? 3 : 2) * (size_t)mc.ngc * NW + prun_n) * sizeof(double));
     unsigned long long top_before = 0;
     HIP_CHECK(hipMemcpyAsync(&top_before, sink->mp.top, sizeof(top_before), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -752,8 +755,8 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         a.want_map = 1;
         a.bstart = (const int *)(cp + o_bs);
         a.Pa = pbuf.as<double>();
-        a.Pb = pbuf.as<double>() + 2 * (size_t)mc.ngc * NW;
-        a.Prun = std::getenv("PHMM_NO_RUNMAX") ? nullptr : pbuf.as<double>() + 3 * (size_t)mc.ngc * NW;
+        a.Pb = need_pb ? pbuf.as<double>() + 2 * (size_t)mc.ngc * NW : pbuf.as<double>();  // (never touched without such a read)
+        a.Prun = std::getenv("PHMM_NO_RUNMAX") ? nullptr : pbuf.as<double>() + (need_pb ? 3 : 2) * (size_t)mc.ngc * NW;
         // backward scratch of the chunk must start clean (a previous attempt may have used it)
         HIP_CHECK(hipMemsetAsync(a.cmaxB, 0, sizeof(unsigned long long) * (size_t)a.ng * a.Lc * W, s));
         HIP_CHECK(hipMemsetAsync(a.pmax, 0, sizeof(unsigned long long) * (size_t)a.ng * (a.Lc + 1) * W, s));

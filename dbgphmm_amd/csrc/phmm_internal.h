@@ -46,6 +46,8 @@ struct DevicePool;
 // DP-table budget of a call: PHMM_MEM_FRACTION (0.9) of what is free plus the pool's own tables (they are
 // re-allocated), less `reserve` bytes the call's other buffers still have to grow by
 uint64_t table_budget(const DevicePool &pool, uint64_t reserve = 0);
+// budget of a call that plans every buffer it uses (sparse_dyn.hip): a fraction of free + everything the pool holds
+uint64_t planned_budget(const DevicePool &pool);
 
 // ---------------------------------------------------------------- device buffers
 struct DevBuf {

@@ -300,6 +300,188 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- candidate batches: several candidates per wave
+// The loop of sample_posterior_once (multi_dbg/posterior.rs:483-515) runs the SAME reads over the SAME lists for
+// every candidate copy-number vector; only init / trans differ.  A mapping list holds ~5 nodes (cfg3: 98.9 % of
+// the positions <= 8, all but 3e-5 <= 16), so one lane per list entry leaves 9 lanes in 10 idle, and a wave per
+// (read, candidate) repeats the whole topology walk -- list, hash, parent lookups -- per candidate.  Here a wave
+// owns one read and G = 64 / WG candidates: lane = (candidate group, list slot), slots < WG.  The list, its hash
+// and the parent / own-previous lookups are done once per position for all groups; per candidate only init[node],
+// trans[edge] and the arithmetic differ; reductions (column maximum, end sum) are segmented over the WG lanes of a
+// group.  Reads whose longest list exceeds WG take the next class (16, 32, then the one-candidate kernels).
+// Same sums in the same order as hinted_lean_kernel: bit-equal results.
+template <int WG> __device__ __forceinline__ double group_max(double v) {
+#pragma unroll
+    for (int off = 1; off < WG; off <<= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+// Sum over the WG lanes of a group in the association of wave_sum (sparse_dev.h: an inclusive Hillis-Steele scan read
+// at the last lane) restricted to the group -- lanes beyond a list are zeros there and here, so a candidate's end
+// sum has the same bits whether its list sat alone on a wave or in a group.
+template <int WG> __device__ __forceinline__ double group_sum(double v, int slot) {
+#pragma unroll
+    for (int off = 1; off < WG; off <<= 1) {
+        const double t = __shfl_up(v, off, WG);
+        v += slot >= off ? t : 0.0;
+    }
+    return __shfl(v, WG - 1, WG);
+}
+
+template <int WG>
+__global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, const uint32_t n_cand) {
+    constexpr int G = 64 / WG;
+    __shared__ HintedLeanShared sh;
+    const int lane = threadIdx.x;
+    const int slot = lane % WG, grp = lane / WG, gbase = grp * WG;
+    const uint32_t rd = a.read_ids[blockIdx.x];
+    uint32_t cand = blockIdx.y * G + (uint32_t)grp;
+    const bool cand_ok = cand < n_cand;
+    if (!cand_ok) cand = n_cand - 1;  // (idle groups of the last wave compute a copy; nothing is written)
+    const double *init = a.init_c + (size_t)cand * a.M.N;
+    const double *trans = a.trans_c + (size_t)cand * a.E;
+    const ParRec *prec = a.M.prec;
+    const LinParams &lp = a.M.lp;
+    const uint64_t b0 = a.read_off[rd];
+    const int len = (int)(a.read_off[rd + 1] - b0);
+    const uint64_t *po = a.map_pos_off + b0;
+    uint32_t err = 0;
+    uint64_t o_cur = po[0], o_nx = po[1], o_n2 = po[len >= 2 ? 2 : 1];
+    int n_cur = (int)(o_nx - o_cur), n_nx = len >= 2 ? (int)(o_n2 - o_nx) : 0;
+    uint32_t id_cur = (slot < n_cur && n_cur <= WG) ? a.map_nodes[o_cur + slot] : 0u;
+    uint32_t id_nx = (slot < n_nx && n_nx <= WG) ? a.map_nodes[o_nx + slot] : 0u;
+    ParRec rc_cur = prec[id_cur];
+    double in_cur = init[id_cur];
+    double w_cur[ADJ_DEG];
+#pragma unroll
+    for (int q = 0; q < ADJ_DEG; q++) w_cur[q] = q < (int)rc_cur.npar ? trans[rc_cur.pedge[q]] : 0.0;
+    uint8_t x_cur = a.bases[b0], x_nx = len >= 2 ? a.bases[b0 + 1] : (uint8_t)0;
+    double pm = 0.0, pi = 0.0, pd = 0.0, m = 0.0, ii = 0.0, d = 0.0, ibs = 0.0;
+    int Eprev = 0, n_prev = 0;
+    for (int pos = 0; pos < len; pos++) {
+        if (n_cur > WG) {
+            err |= SP_ERR_CAPACITY;
+            break;
+        }
+        // ---- requests for the positions ahead
+        const ParRec rc_nx = prec[id_nx];
+        const double in_nx = init[id_nx];
+        const uint64_t o_n3 = po[pos + 3 <= len ? pos + 3 : len];
+        const int n_n2 = pos + 2 < len ? (int)(o_n3 - o_n2) : 0;
+        const uint32_t id_n2 = (slot < n_n2 && n_n2 <= WG) ? a.map_nodes[o_n2 + slot] : 0u;
+        const uint8_t x_n2 = pos + 2 < len ? a.bases[b0 + pos + 2] : (uint8_t)0;
+        // ---- hash of this position's list: node -> slot (group 0 inserts; every group reads)
+        const bool first = pos == 0;
+        const int n = n_cur;
+        const bool has = slot < n;
+        uint2 *hc = sh.ent[pos & 1];
+        const uint2 *hp = sh.ent[(pos + 1) & 1];
+        for (int h = lane; h < HL_HASH; h += 64) hc[h].x = 0xffffffffu;
+        wave_sync();
+        if (has && grp == 0) {
+            uint32_t h = hl_hash(id_cur);
+            for (;;) {
+                const uint32_t old = atomicCAS(&hc[h].x, 0xffffffffu, id_cur);
+                if (old == 0xffffffffu) break;
+                if (old == id_cur) {
+                    err |= SP_ERR_DUPLICATE;
+                    break;
+                }
+                h = (h + 1) & (HL_HASH - 1);
+            }
+            hc[h].y = (uint32_t)slot;
+        }
+        wave_sync();
+        // ---- fm, fi (forward.rs:337-388), fib (541-545)
+        const double c_begin = first ? lp.p_MM : lp.p_IM * ibs;
+        const double ib_cur = first ? lp.p_random * lp.p_MI : lp.p_random * lp.p_II * ibs;
+        const double c_del = lp.p_ID * ib_cur;
+        const bool hadp = slot < n_prev;
+        const double Gv = hadp ? lp.p_MM * pm + lp.p_IM * pi + lp.p_DM * pd : 0.0;
+        const double Hv = hadp ? lp.p_MI * pm + lp.p_II * pi + lp.p_DI * pd : 0.0;
+        int ps[ADJ_DEG], cs[ADJ_DEG];
+        uint32_t anyq = 0;  // wave-uniform: some lane has a q-th parent (on a DBG mostly q = 0 only)
+#pragma unroll
+        for (int q = 0; q < ADJ_DEG; q++) {
+            // (the topology test only: a candidate whose weight is 0 multiplies by it -- the one-candidate kernel
+            // skips such a parent, which adds the same +0.0)
+            const bool use = has && q < (int)rc_cur.npar;
+            ps[q] = cs[q] = -1;
+            if (__ballot(use) != 0ull) {
+                anyq |= 1u << q;
+                ps[q] = (use && !first) ? hl_find(hp, rc_cur.par[q]) : -1;
+                cs[q] = use ? hl_find(hc, rc_cur.par[q]) : -1;
+            }
+        }
+        const int os = (has && !first) ? hl_find(hp, id_cur) : -1;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < ADJ_DEG; q++) {
+            if (!(anyq & (1u << q))) continue;
+            const double v = __shfl(Gv, gbase + (ps[q] < 0 ? 0 : ps[q]));
+            if (ps[q] >= 0 && w_cur[q] != 0.0) acc += w_cur[q] * v;
+        }
+        const double hv = __shfl(Hv, gbase + (os < 0 ? 0 : os));
+        m = ii = d = 0.0;
+        if (has) {
+            const double pe = rc_cur.emis == x_cur ? lp.p_match : lp.p_mismatch;
+            m = pe * (acc + in_cur * c_begin);
+            ii = os >= 0 ? lp.p_random * hv : 0.0;
+        }
+        // ---- fd0 + n_max_gaps x fdt restricted to the list (forward.rs:423-524)
+        double lv = lp.p_MD * m + lp.p_ID * ii;
+        for (int t = 0; t <= lp.n_max_gaps; t++) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < ADJ_DEG; q++) {
+                if (!(anyq & (1u << q))) continue;
+                const double v = __shfl(lv, gbase + (cs[q] < 0 ? 0 : cs[q]));
+                if (cs[q] >= 0 && w_cur[q] != 0.0) sacc += w_cur[q] * v;
+            }
+            if (t == 0) sacc += in_cur * c_del;
+            else sacc *= lp.p_DD;
+            sacc = has ? sacc : 0.0;
+            d += sacc;
+            lv = sacc;
+        }
+        // ---- rescale so that the column maximum of THIS candidate is in [0.5, 1)
+        const double mx = group_max<WG>(fmax(has ? fmax(fmax(m, ii), d) : 0.0, ib_cur));
+        const int e = sp_exp_of(mx);
+        const double sc = sp_pow2(-e);
+        m *= sc;
+        ii *= sc;
+        d *= sc;
+        const int Ecur = (first ? 0 : Eprev) + e;
+        ibs = ib_cur * sc;
+        // ---- the column becomes the previous one; weights of the next position (its record has arrived)
+        pm = m;
+        pi = ii;
+        pd = d;
+        Eprev = Ecur;
+        n_prev = n;
+#pragma unroll
+        for (int q = 0; q < ADJ_DEG; q++) w_cur[q] = q < (int)rc_nx.npar ? trans[rc_nx.pedge[q]] : 0.0;
+        o_cur = o_nx;
+        o_nx = o_n2;
+        o_n2 = o_n3;
+        n_cur = n_nx;
+        n_nx = n_n2;
+        id_cur = id_nx;
+        id_nx = id_n2;
+        rc_cur = rc_nx;
+        in_cur = in_nx;
+        x_cur = x_nx;
+        x_nx = x_n2;
+    }
+    for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
+    // fe (forward.rs:554-558) of the last column, per candidate
+    const double stot = group_sum<WG>(slot < n_prev ? pm + pi + pd : 0.0, slot);
+    const double lpv = err ? NAN : log(lp.p_end * stot) + (double)Eprev * SP_LN2;
+    if (slot == 0 && cand_ok) {
+        a.out_logp[(size_t)cand * a.R + rd] = lpv;
+        a.err[(size_t)cand * a.R + rd] = err;
+    }
+}
+
 __global__ void __launch_bounds__(256) exp_kernel(const double *in, double *out, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
@@ -468,12 +650,16 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
         d_trans = cand_trans.as<double>();
     }
 
-    // capacity classes by the longest node list of each read
-    std::vector<uint32_t> cls[3];
+    // capacity classes by the longest node list of each read.  Candidate batches: reads with short lists go to the
+    // packed kernels (several candidates per wave) first.
+    std::vector<uint32_t> cls[3], pcls[3];
     uint64_t cells = 0;
+    const bool lean_ok = m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
+    const bool packed_ok = n_cand >= 2 && !pool && lean_ok && std::getenv("PHMM_NO_PACKED") == nullptr;
     for (uint64_t r = 0; r < R; r++) {
         const uint32_t mx = mp->read_max_list[r];
-        cls[mx <= 64 ? 0 : (mx <= 128 ? 1 : 2)].push_back((uint32_t)r);
+        if (packed_ok && mx <= 32) pcls[mx <= 8 ? 0 : (mx <= 16 ? 1 : 2)].push_back((uint32_t)r);
+        else cls[mx <= 64 ? 0 : (mx <= 128 ? 1 : 2)].push_back((uint32_t)r);
     }
     DevBuf &d_ids = m->wset().aux[10], &d_out = m->wset().aux[11], &d_err = m->wset().aux[12];
     d_ids.reserve(R * sizeof(uint32_t));
@@ -499,9 +685,28 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
 
     EvTimer tm(timing_enabled());
     for (int c = 0; c < 3; c++) {
+        if (pcls[c].empty()) continue;
+        HIP_CHECK(hipMemcpyAsync(d_ids.p, pcls[c].data(), pcls[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        const unsigned nr = (unsigned)pcls[c].size();
+        if (c == 0) hipLaunchKernelGGL(hinted_packed_kernel<8>, dim3(nr, (n_cand + 7) / 8), dim3(64), 0, s, a, n_cand);
+        else if (c == 1) hipLaunchKernelGGL(hinted_packed_kernel<16>, dim3(nr, (n_cand + 3) / 4), dim3(64), 0, s, a, n_cand);
+        else hipLaunchKernelGGL(hinted_packed_kernel<32>, dim3(nr, (n_cand + 1) / 2), dim3(64), 0, s, a, n_cand);
+        HIP_CHECK(hipGetLastError());
+        st.launches[2]++;
+        HIP_CHECK(hipMemcpyAsync(h_err.data(), d_err.p, h_err.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));  // (the read-id list is reused by the next class)
+        for (uint32_t rd : pcls[c]) {
+            uint32_t e = 0;
+            for (uint32_t k = 0; k < n_cand; k++) e |= h_err[(size_t)k * R + rd];
+            if (!e) continue;
+            if (e & SP_ERR_DUPLICATE) PHMM_THROW(PHMM_EINVAL, "duplicate node in a mapping list");
+            cls[0].push_back(rd);  // (cannot happen with read_max_list right: the one-candidate kernels take it)
+        }
+    }
+    for (int c = 0; c < 3; c++) {
         if (cls[c].empty()) continue;
         HIP_CHECK(hipMemcpyAsync(d_ids.p, cls[c].data(), cls[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        if (c == 0 && m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr) {
+        if (c == 0 && lean_ok) {
             hipLaunchKernelGGL(hinted_lean_kernel, dim3((unsigned)cls[c].size(), n_cand), dim3(64), 0, s, a);
         } else if (c == 0) launch_hinted<64, 2>(a, (uint32_t)cls[c].size(), n_cand);
         else if (c == 1) launch_hinted<128, 4>(a, (uint32_t)cls[c].size(), n_cand);
@@ -522,6 +727,8 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
             else PHMM_THROW(PHMM_ECAPACITY, "mapping list needs more than 400 slots / 8 in-list parents");
         }
     }
+    HIP_CHECK(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
     st.ms[2] += tm.stop();
     cells = mp->total_entries;
     st.cells[2] = cells * n_cand;

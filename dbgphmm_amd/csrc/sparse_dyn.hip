@@ -402,25 +402,43 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     if (const char *e = std::getenv("PHMM_WARM_COLS")) warm_cols = std::max(4, std::atoi(e));
     int chunk_groups = 0;  // 0: automatic
     if (const char *e = std::getenv("PHMM_CHUNK_GROUPS")) chunk_groups = std::max(0, std::atoi(e));
-    // Memory plan of the call, fixed HERE (nothing below reads the free-memory counter again): the pool's other
-    // buffers are grow-only and reused, so what they still have to grow by for this read set is set aside first --
-    // forward record pool (~1 KB per sparse position), mapping sink, control arrays; the emit-prob planes of the
-    // mapping flow scale with the read groups and are part of the per-group cost below.  Of the rest, 1/8 is the
-    // budget of the deferred reads' plan (it runs BESIDE the main plan on its own stream and workspace set).
-    uint64_t aux_need = 0;
+    // Memory plan of the call, fixed HERE (nothing below reads the free-memory counter again).  The budget is a share
+    // of free + pool-owned bytes (the pool's buffers are grow-only and reused: all of it is this call's to use).
+    // Set aside first: what the buffers that do not scale with the read groups need for this read set -- forward
+    // record pool (~1 KB per sparse position, once per workspace set in use), mapping sink, control arrays, top-400
+    // scratch -- or what they already hold if that is more.  The emit-prob planes of the mapping flow scale with the
+    // groups and are part of the per-group cost below.  Then the deferred reads' plan (it runs BESIDE the main plan
+    // on its own stream and workspace set): what the reads that needed more than the kept columns last time would
+    // take with all n_warmup + 2 columns (no hints yet: 2 % of the reads), padded by a quarter, at most 1/8.  Too
+    // small a share only cuts that plan into more chunks (or sends it behind the main plan), never fails.
+    uint64_t min_len = UINT64_MAX;
+    for (uint64_t r = 0; r < R; r++) min_len = std::min<uint64_t>(min_len, reads->off[r + 1] - reads->off[r]);
+    // the plane of merged index `len` (Pb) is only written for reads that end inside the dense columns
+    const int map_planes = sink ? (min_len <= (uint64_t)prm.n_warmup + 2 ? 3 : 2) : 0;
+    uint64_t limit_total = 0, limit_side = 0;
     {
         const uint64_t est_fpool = reads->total * 1024 + R * 65536 + (1u << 20), est_meta = reads->total * 40,
                        est_ctl = R * (uint64_t)(PHMM_MAX_ACTIVE_NODES * 12 * 5 + WF_CAP * 12 + 4096) + reads->total,
                        est_sink = sink ? reads->total * 176 + R * 131072 + (1u << 21) : 0,
                        est_sel = (uint64_t)256 * m->N * 12;
-        const uint64_t est = 2 * (est_fpool + est_meta + est_ctl) / (sink ? 1 : 2) + est_sink + est_sel;
-        uint64_t have = 0;
-        for (const auto &w : m->pool->wsets)
-            for (const auto &b : w.aux) have += b.bytes;
-        aux_need = est > have ? est - have : 0;
+        const uint64_t est = (est_fpool + est_meta + est_ctl) * 5 / 4 + est_sink + est_sel;
+        uint64_t have = m->pool->ws_out.bytes;
+        for (const auto &w : m->pool->wsets) {
+            have += w.misc.bytes;
+            for (int k = 0; k < 16; k++)
+                if (k != 4) have += w.aux[k].bytes;  // (aux[4]: the emit-prob planes, per-group cost)
+        }
+        const uint64_t total = planned_budget(*m->pool), fixed = std::max(est, have);
+        limit_total = total > fixed + ((uint64_t)64 << 20) ? total - fixed : (uint64_t)64 << 20;
+        uint64_t n_def = std::max<uint64_t>(8, R / 50);
+        if (by_ratio && reads->warm_hint.size() == R) {
+            n_def = 8;
+            for (uint16_t h : reads->warm_hint) n_def += h >= warm_cols ? 1 : 0;
+        }
+        const uint64_t per_read = ((uint64_t)(prm.n_warmup + 2) * 24 + 4 * 8 + (uint64_t)map_planes * 8) * m->N;
+        limit_side = std::min<uint64_t>(limit_total / 8, n_def * per_read * 5 / 4);
     }
-    const uint64_t limit_total = table_budget(*m->pool, aux_need);
-    const uint64_t limit_side = limit_total / 8, limit_main = limit_total - limit_side;
+    const uint64_t limit_main = limit_total - limit_side;
 
     // cut a plan into items (caller holds `mu` or is the only thread)
     auto enqueue_plan = [&](std::unique_ptr<PlanCtx> pcu, std::deque<Item> &dst) {
@@ -444,9 +462,20 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         while (g0 < plan.ng_total) {
             // dense columns kept: at most n_warmup (+1 so that the launch that writes d of the last
             // dense column has somewhere to put its speculative next column)
-            const int Lc = (int)std::min<int64_t>((int64_t)pc->max_len, std::min<int64_t>(prm.n_warmup + 2, pc->lc_cap));
+            int Lc = (int)std::min<int64_t>((int64_t)pc->max_len, std::min<int64_t>(prm.n_warmup + 2, pc->lc_cap));
+            if (pc->may_defer && g0 == 0 && n_workers == 1) {
+                // A main plan that misses one chunk by a little keeps a column or two less instead (a few more reads
+                // are deferred to the side plan, which runs beside it) -- a second chunk would add its whole
+                // latency-bound frontier phase to the critical path.
+                auto cost = [&](int lc) { return (size_t)lc * NW * 24 + 4 * NW * 8 + (sink ? (size_t)map_planes * NW * 8 + (size_t)plan.nblk8 * BLOCK * 8 : 0); };
+                for (int cut = 0; cut <= 2 && Lc - cut >= 8; cut++)
+                    if ((uint64_t)plan.ng_total * cost(Lc - cut) <= limit) {
+                        Lc -= cut;
+                        break;
+                    }
+            }
             // tables + (mapping flow) three emit-prob planes and the per-run maxima (mapping_flow.hip: pbuf)
-            const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8 + (sink ? 3 * NW * 8 + (size_t)plan.nblk8 * BLOCK * 8 : 0);
+            const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8 + (sink ? (size_t)map_planes * NW * 8 + (size_t)plan.nblk8 * BLOCK * 8 : 0);
             int ngc = (int)std::min<uint64_t>(plan.ng_total - g0, std::max<uint64_t>(1, limit / std::max<size_t>(per_group, 1)));
             ngc = std::min(ngc, std::max(1, target));
             // longest read of the chunk (the order need not be by length)
@@ -653,7 +682,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         if (!deferred_ids.empty()) {
             std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan_ids(m, reads, deferred_ids), (int64_t)prm.n_warmup + 2, false, {}});
             // (a group of the deferred plan that does not fit the side budget waits for the main plan's tables instead)
-            const size_t side_group = ((size_t)(prm.n_warmup + 2) * 24 + 4 * 8 + (sink ? 3 * 8 : 0)) * m->N * pc->plan.W;
+            const size_t side_group = ((size_t)(prm.n_warmup + 2) * 24 + 4 * 8 + (size_t)map_planes * 8) * m->N * pc->plan.W;
             std::lock_guard<std::mutex> lk(mu);
             if (single_mode && side_on && side_group <= limit_side) {
                 enqueue_plan(std::move(pc), side_queue);

@@ -111,6 +111,32 @@ def test_cfg3_two_live_models(cfg3):
     assert np.array_equal(lp_s2, lp_s)
 
 
+def test_cfg3_candidate_batch_packs_candidates(cfg3, monkeypatch):
+    """The inner loop of `infer` (multi_dbg/posterior.rs:483-515) on the cfg3 mappings: a batch of candidates runs
+    several candidates per wave (sparse.hip: hinted_packed_kernel); every candidate's per-read ln P has the bits of
+    its one-candidate evaluation, whatever its place in the batch."""
+    import bench
+    arrays, rc, mp, gm = cfg3["arrays"], cfg3["rc"], cfg3["mp"], cfg3["gm"]
+    sg = bench.cfg_seq_graph("cfg3")
+    rng = np.random.default_rng(11)
+    C = 11  # (not a multiple of the candidates per wave: the last wave of a read is partly idle)
+    cn = np.repeat(sg.copy_num.astype(np.uint32)[None, :], C, axis=0)
+    for c in range(1, C):
+        ix = rng.integers(0, cn.shape[1], size=40)
+        cn[c, ix] = np.maximum(cn[c, ix].astype(np.int64) + rng.choice([-1, 1], size=40), 0).astype(np.uint32)
+    tot, lp = gm.to_full_prob_reads_copy_nums(rc, mp, cn, 0)
+    assert np.isneginf(lp[1:]).any() and np.all(np.isfinite(lp[0]))  # a k-mer set to 0 kills the reads through it
+    for c in (0, 4, 10):
+        t1, lp1 = gm.to_full_prob_reads_copy_nums(rc, mp, cn[c:c + 1], 0)  # one candidate: the one-candidate kernels
+        assert np.array_equal(lp1[0], lp[c]) and (t1[0] == tot[c] or (np.isneginf(t1[0]) and np.isneginf(tot[c])))
+    monkeypatch.setenv("PHMM_NO_PACKED", "1")
+    tot2, lp2 = gm.to_full_prob_reads_copy_nums(rc, mp, cn, 0)
+    assert np.array_equal(lp2, lp)
+    # candidate 0 carries the graph's own copy numbers: the mapping model's hinted likelihood
+    _, lp_h = gm.to_full_prob_reads(rc, mp)
+    assert np.max(np.abs(lp[0] - lp_h)) < 1e-9
+
+
 def test_cfg3_small_workspace_limit(cfg3):
     """The same read set under a 24 GB table budget (many chunks; deferred reads' plan inside its fixed share):
     same bits as the one-chunk run."""
