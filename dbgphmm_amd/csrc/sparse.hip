@@ -310,9 +310,23 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
 // trans[edge] and the arithmetic differ; reductions (column maximum, end sum) are segmented over the WG lanes of a
 // group.  Reads whose longest list exceeds WG take the next class (16, 32, then the one-candidate kernels).
 // Same sums in the same order as hinted_lean_kernel: bit-equal results.
+// maximum of NON-NEGATIVE values over the WG lanes of a group, in every lane, on the DPP path (VALU moves, no LDS
+// round trips -- the kernel is VALU-issue bound, profiles/r2_candidates64_sq_counters.txt, and a __shfl_xor of a
+// double is two ds_bpermute plus their address arithmetic): quad permutes and the half-row mirror for 8 lanes, row
+// rotations for a row of 16, one cross-row shuffle on top for 32.
 template <int WG> __device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-    for (int off = 1; off < WG; off <<= 1) v = fmax(v, __shfl_xor(v, off));
+    static_assert(WG == 8 || WG == 16 || WG == 32, "group width");
+    if (WG == 8) {
+        v = fmax(v, dpp_d<0xB1, 0xf>(0.0, v));   // quad_perm [1,0,3,2]
+        v = fmax(v, dpp_d<0x4E, 0xf>(0.0, v));   // quad_perm [2,3,0,1]
+        v = fmax(v, dpp_d<0x141, 0xf>(0.0, v));  // row_half_mirror: the other quad of the 8
+        return v;
+    }
+    v = fmax(v, dpp_d<0x128, 0xf>(0.0, v));  // row_ror 8, 4, 2, 1
+    v = fmax(v, dpp_d<0x124, 0xf>(0.0, v));
+    v = fmax(v, dpp_d<0x122, 0xf>(0.0, v));
+    v = fmax(v, dpp_d<0x121, 0xf>(0.0, v));
+    if (WG == 32) v = fmax(v, __shfl_xor(v, 16));
     return v;
 }
 // Sum over the WG lanes of a group in the association of wave_sum (sparse_dev.h: an inclusive Hillis-Steele scan read

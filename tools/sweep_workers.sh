@@ -1,7 +1,9 @@
 #!/bin/bash
-# dev: cfg3 bench for a few pipeline settings
-for cfg in "1 0" "2 0" "2 16" "2 27" "3 0" "3 12" "3 16" "4 8"; do
+out=gpurun_out/r2_workers.log
+: > $out
+for cfg in "1 0" "2 32" "2 21" "2 16" "3 21" "3 11"; do
   set -- $cfg
-  echo "== workers $1 chunk_groups $2"
-  PHMM_WORKERS=$1 PHMM_CHUNK_GROUPS=$2 timeout -k 10 200 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms/step %.1f  bwd %.0f GB/s (%.0f us)  fwd %.0f GB/s' % (d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_launch_us'], d['roofline']['fwd_step']['achieved']))"
+  echo "== WORKERS=$1 CHUNK_GROUPS=$2" >> $out
+  PHMM_WORKERS=$1 PHMM_CHUNK_GROUPS=$2 timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline >> $out 2>&1 || exit 1
 done
+python3 tools/show_sweep.py $out
