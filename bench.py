@@ -43,6 +43,8 @@ WORKLOADS = {
     "cfg2": dict(genome=10_000, haplotypes=1, k=40, coverage=20, read_len=1000, p=0.001, mode="dense",
                  desc="cfg2: synthetic 10 kb haploid genome, 20x HiFi reads (p=0.001, L=1000), k=40 DBG, "
                       "dense forward+backward+node posteriors"),
+    "cfg1m": dict(genome=5_000, haplotypes=2, k=16, coverage=10, read_len=200, p=0.001, mode="sparse",
+                  desc="cfg1m: 5 kb diploid, 10x, L=200, k=16, sparse-adaptive flow (small: tests and rehearsals)"),
     "cfg1": dict(genome=1_000, haplotypes=1, k=16, coverage=10, read_len=200, p=0.001, mode="dense",
                  desc="cfg1: 1 kb haploid, 10x, L=200, k=16, dense forward+backward"),
 }
@@ -256,7 +258,15 @@ def main():
     _ffi.check(L.phmm_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     L.phmm_enable_timing(1)
 
-    arrays, reads, w = build_workload(args.workload, rank, world, args.scaling)
+    cand_range = None
+    if args.mode == "candidates" and world > 1:
+        # 2-D split: candidates first (no reduction), reads only when there are fewer candidates than ranks
+        arrays, all_reads, w = build_workload(args.workload, 0, 1, "strong")
+        grid = PD.shard_grid(args.candidates, [len(r) for r in all_reads], world)
+        cand_range, (rlo, rhi) = grid[rank]
+        reads = all_reads[rlo:rhi]
+    else:
+        arrays, reads, w = build_workload(args.workload, rank, world, args.scaling)
     model = D.PHMMModel(arrays)
     rc = D.ReadCollection(reads)
     n_bases = rc.total_bases()
@@ -278,7 +288,7 @@ def main():
     cand = None
     if args.mode == "candidates":
         if w["mode"] != "sparse":
-            raise SystemExit("--mode candidates runs on the cfg3 workload")
+            raise SystemExit("--mode candidates runs on a sparse-flow workload (cfg3, cfg1m)")
         # candidates the way the sampler makes them: the current copy numbers with a few k-mers moved by +-1
         # (neighbour cycles of multi_dbg/neighbors.rs change a handful of edges); to_phmm semantics (min 0)
         sg = cfg_seq_graph(args.workload)
@@ -287,15 +297,23 @@ def main():
         for c in range(1, args.candidates):
             ix = rng.integers(0, N, size=16)
             cn[c, ix] = np.maximum(cn[c, ix].astype(np.int64) + rng.choice([-1, 1], size=16), 0).astype(np.uint32)
-        cand = np.ascontiguousarray(cn)
+        c_lo, c_hi = cand_range if cand_range else (0, args.candidates)
+        cand = np.ascontiguousarray(cn[c_lo:c_hi])
         mp0, _ = model.generate_mappings(rc, None, True)
         state["mappings"] = mp0
-        cand_tot = np.empty(args.candidates)
+        cand_tot = torch.zeros(args.candidates, dtype=torch.float64, device=dev)  # the one vector that is all-reduced
 
     def step():
         if args.mode == "candidates":
             tot, _ = model.to_full_prob_reads_copy_nums(rc, state["mappings"], cand, 0)
-            cand_tot[:] = tot
+            cand_tot.zero_()
+            cand_tot[c_lo:c_hi] = torch.from_numpy(tot).to(dev)
+            if dist is not None:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                PD.all_reduce_partial(cand_tot, dist)  # sum over the read shards of every candidate
+                torch.cuda.synchronize()
+                state["ar_ms"] += (time.perf_counter() - t0) * 1e3
             return
         if w["mode"] == "dense":
             model.run_dense(rc, True, True, out_logp=out_logp, out_node_freq=red[1:])
@@ -354,6 +372,11 @@ def main():
         per_rank_ms = [float(x) for x in gathered]
     else:
         total_bases = float(n_bases)
+    if args.mode == "candidates" and world > 1:
+        # every (candidate, base) pair is computed once: candidates x bases of the one read set
+        cand_work = float(args.candidates) * float(sum(len(r) for r in all_reads))
+    else:
+        cand_work = float(args.candidates) * total_bases
 
     extra = {}
     if w["mode"] == "sparse" and rank == 0 and args.mode == "mapping":
@@ -400,15 +423,17 @@ def main():
             # the list (the column itself lives in registers / LDS), so HBM is not what bounds it -- reported as
             # instruction-issue / latency bound with the SQ counters of profiles/ 
             mp = state["mappings"]
-            cells = int(mp.arrays()[1].shape[0]) * args.candidates
+            cells = int(mp.arrays()[1].shape[0]) * int(cand.shape[0])
             ms, n, _c = acc[2]
             out = {"metric": "candidate-read-bases/sec through the hinted forward P(R|X') (inner loop of infer)",
-                   "value": total_bases * args.candidates * args.steps / dt, "unit": "candidate-bases/s", **common,
+                   "value": cand_work * args.steps / dt, "unit": "candidate-bases/s", **common,
                    "config": {"workload": w["desc"] + f"; {args.candidates} candidate copy-number vectors x all reads, "
                               "init/trans built on the device (phmm_full_prob_reads_copy_nums)",
-                              "candidates": args.candidates, "n_nodes": N, "reads": len(rc), "bases": n_bases,
+                              "candidates": args.candidates, "candidates_rank0": int(cand.shape[0]), "n_nodes": N, "reads_rank0": len(rc), "bases_rank0": n_bases,
                               "list_cells_per_step": cells, "upload_bytes_per_step": int(cand.nbytes),
-                              "sum_lnP_candidate0": float(cand_tot[0])},
+                              "sum_lnP_candidate0": float(cand_tot[0]), "per_rank_ms": per_rank_ms,
+                              "all_reduce_ms_per_step": state["ar_ms"] / max(args.steps, 1), "backend": backend,
+                              "grid": "candidates x read shards (dist.shard_grid)" if world > 1 else "one GPU"},
                    "roofline": {"bound": "hbm", "achieved": 4.0 * cells * args.steps / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                                 "frac": 4.0 * cells * args.steps / dt / 1e9 / 8000.0, "traffic": None,
                                 "kernel": "hinted_lean_kernel", "algorithmic_bytes_per_launch": 4.0 * cells,

@@ -678,13 +678,15 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                     hl[gi] = 0;  // not part of this chunk any more
                 }
         }
-        // hand the deferred reads over NOW: their small plan runs on the side stream under the rest of this chunk
-        if (!deferred_ids.empty()) {
-            std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan_ids(m, reads, deferred_ids), (int64_t)prm.n_warmup + 2, false, {}});
-            // (a group of the deferred plan that does not fit the side budget waits for the main plan's tables instead)
+        // A small plan of reads this chunk gives up (all n_warmup + 2 columns, nothing deferred again) runs on the side
+        // stream under the rest of this chunk; where that is not possible it queues behind the main plan.
+        auto hand_over = [&](const std::vector<uint32_t> &ids) -> bool {
+            std::unique_ptr<PlanCtx> pc(new PlanCtx{make_plan_ids(m, reads, ids), (int64_t)prm.n_warmup + 2, false, {}});
+            // (a group of that plan that does not fit the side budget waits for the main plan's tables instead)
             const size_t side_group = ((size_t)(prm.n_warmup + 2) * 24 + 4 * 8 + (size_t)map_planes * 8) * m->N * pc->plan.W;
             std::lock_guard<std::mutex> lk(mu);
-            if (single_mode && side_on && side_group <= limit_side) {
+            const bool beside = single_mode && side_on && side_group <= limit_side;
+            if (beside) {
                 enqueue_plan(std::move(pc), side_queue);
                 if (!side_started) {
                     side_started = true;
@@ -694,7 +696,10 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 enqueue_plan(std::move(pc), queue);
             }
             cv.notify_all();
-        }
+            return beside;
+        };
+        // hand the deferred reads over NOW
+        if (!deferred_ids.empty()) hand_over(deferred_ids);
         std::vector<uint32_t> sparse_lanes, need400;
         for (int gi = 0; gi < lanes; gi++) {
             if (hl[gi] == 0) continue;
@@ -830,6 +835,24 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                         if (hstop[gi] < hl[gi]) next.push_back(gi);
                     }
                     todo.swap(next);
+                    if (round == 1 && phase == 1 && !pool_full && !todo.empty() && deferred && by_ratio && single_mode && side_on &&
+                        todo.size() <= std::max<size_t>(8, (size_t)lanes / 64) && std::getenv("PHMM_NO_WIDE_HANDOVER") == nullptr) {
+                        // The few reads whose frontier outgrew the one-lane-per-node class (5 of 4 026 on cfg3) would
+                        // now take a 400-slot burst and then walk the rest of the read ALONE -- 6 ms of pure latency
+                        // on this chunk's critical path, and as much again in the backward pass.  They leave the
+                        // chunk instead and are done from their first base in a plan of their own on the side stream,
+                        // beside this chunk's backward phases (the same route the deferred reads take).
+                        std::vector<uint32_t> ids;
+                        for (uint32_t gi : todo) ids.push_back(plan.order[(size_t)g0 * W + gi]);
+                        for (uint32_t rd : ids) new_flags[rd] |= PHMM_READ_WIDE_FRONTIER;
+                        for (uint32_t gi : todo) hl[gi] = 0;  // not part of this chunk any more
+                        sparse_lanes.erase(std::remove_if(sparse_lanes.begin(), sparse_lanes.end(), [&](uint32_t gi) { return hl[gi] == 0; }),
+                                           sparse_lanes.end());
+                        HIP_CHECK(hipMemcpyAsync((void *)a.len, hl.data(), hl.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                        hand_over(ids);
+                        if (std::getenv("PHMM_TRACE")) std::fprintf(stderr, "      %zu wide reads handed to a plan of their own\n", ids.size());
+                        todo.clear();
+                    }
                     trace(phase == 0 ? "   phase A <400>" : (phase == 1 ? "   phase B <64>" : "   phase C <400>"));
                     if (std::getenv("PHMM_TRACE")) std::fprintf(stderr, "      remaining lanes %zu\n", todo.size());
                 }

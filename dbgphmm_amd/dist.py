@@ -27,6 +27,24 @@ def shard_reads(lengths: Sequence[int], world_size: int) -> List[Tuple[int, int]
     return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
 
 
+def shard_grid(n_candidates: int, lengths: Sequence[int], world_size: int):
+    """2-D split of a candidate batch (multi_dbg/posterior.rs:504-515: candidates x reads are all independent):
+    the ranks form a pc x pr grid, pc = the largest divisor of world_size that is <= n_candidates -- splitting
+    candidates needs no reduction at all -- and the reads are cut pr ways only when there are fewer candidates than
+    ranks.  -> per rank ((cand_lo, cand_hi), (read_lo, read_hi)); rank = cand_shard * pr + read_shard.
+    The per-candidate totals are completed by ONE sum all-reduce of a [n_candidates] vector in which every rank
+    fills the candidates it owns with the sum over its reads."""
+    pc = max(d for d in range(1, world_size + 1) if world_size % d == 0 and d <= max(n_candidates, 1))
+    pr = world_size // pc
+    reads = shard_reads(lengths, pr)
+    out = []
+    for rank in range(world_size):
+        c, r = divmod(rank, pr)
+        lo, hi = n_candidates * c // pc, n_candidates * (c + 1) // pc
+        out.append(((lo, hi), reads[r]))
+    return out
+
+
 def pack_partial(total_logp: float, node_freq: np.ndarray) -> np.ndarray:
     buf = np.empty(1 + node_freq.shape[0], dtype=np.float64)
     buf[0] = total_logp

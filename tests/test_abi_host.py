@@ -52,6 +52,19 @@ def test_product_path_fails_loudly_without_gpu():
     assert e.value.code == _ffi.PHMM_ENODEVICE
 
 
+def test_workspace_and_read_info_entry_points_without_a_call():
+    import ctypes as C
+    lib = _ffi.lib()
+    rc = D.ReadCollection([b"ACGT", b"GG"])
+    cols, flags = np.zeros(2, np.uint16), np.zeros(2, np.uint32)
+    # nothing has run on these reads yet
+    assert lib.phmm_reads_last_call_info(rc._h, cols.ctypes.data_as(C.c_void_p), flags.ctypes.data_as(C.c_void_p)) == _ffi.PHMM_EINVAL
+    assert lib.phmm_reads_last_call_info(None, None, None) == _ffi.PHMM_EINVAL
+    if lib.phmm_device_count() == 0:
+        assert lib.phmm_workspace_bytes() == 0
+        assert lib.phmm_release_workspace() == _ffi.PHMM_ENODEVICE  # no CPU stand-in for the device pool either
+
+
 def test_reads_validation_is_host_side():
     rc = D.ReadCollection([b"ACGT", b"GG"])
     assert len(rc) == 2 and rc.total_bases() == 6

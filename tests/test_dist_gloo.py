@@ -26,6 +26,21 @@ def test_shard_reads_balanced_and_complete():
     assert PD.shard_reads([5], 2)[0][1] - PD.shard_reads([5], 2)[0][0] + PD.shard_reads([5], 2)[1][1] - PD.shard_reads([5], 2)[1][0] == 1
 
 
+def test_shard_grid_covers_every_candidate_read_pair_once():
+    rng = np.random.default_rng(1)
+    lens = rng.integers(50, 1000, size=57).tolist()
+    for C, ws in ((64, 8), (3, 8), (1, 4), (5, 6), (7, 1), (256, 2)):
+        grid = PD.shard_grid(C, lens, ws)
+        assert len(grid) == ws
+        cover = np.zeros((C, len(lens)), dtype=int)
+        for (c0, c1), (r0, r1) in grid:
+            cover[c0:c1, r0:r1] += 1
+        assert np.all(cover == 1)
+        # candidates are split first: reads are only cut when there are fewer candidates than ranks
+        n_read_shards = len({rr for _, rr in grid})
+        assert n_read_shards == 1 or C < ws
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -62,3 +62,19 @@ def test_bench_gpus_2_starts_two_ranks(gpu_lib, scaling):
         assert j2["config"]["bases_rank0"] < j1["config"]["bases_rank0"]
     else:
         assert j2["config"]["total_bases"] > 1.8 * j1["config"]["total_bases"]
+
+
+def test_bench_candidates_two_ranks_split_the_batch(gpu_lib):
+    """--mode candidates --gpus 2: the candidates are dealt to the ranks (dist.shard_grid), one all-reduce of the
+    [C] totals; candidate 0's total equals the one-GPU run's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg1m", "--mode", "candidates", "--candidates", "6",
+            "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run(base + ["--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    j2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["config"]["candidates_rank0"] == 3 and j1["config"]["candidates_rank0"] == 6
+    assert abs(j2["config"]["sum_lnP_candidate0"] - j1["config"]["sum_lnP_candidate0"]) < 1e-9
