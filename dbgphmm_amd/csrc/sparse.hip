@@ -96,6 +96,34 @@ __device__ __forceinline__ int hl_find(const uint2 *ent, uint32_t id) {
 }
 __device__ __forceinline__ double hl_shfl(double v, int src) { return __shfl(v, src < 0 ? 0 : src); }
 
+// The arithmetic of one list entry, written with explicit roundings (no operand order or fma contraction is left to the
+// compiler): hinted_lean_kernel and hinted_packed_kernel<WG, CPL> call these and nothing else on values, so a
+// candidate's score has the same bits whichever kernel, group or lane slot evaluated it.
+struct HStep {
+    // G = p_MM m + p_IM i + p_DM d of the previous column (what flows into Match), H likewise into Ins
+    static __device__ __forceinline__ double lin3(double a, double x, double b, double y, double c, double z) {
+        return __fma_rn(c, z, __fma_rn(b, y, __dmul_rn(a, x)));
+    }
+    static __device__ __forceinline__ double acc(double w, double v, double s) { return __fma_rn(w, v, s); }
+    // fm: e_k(x) (sum + init c_begin)
+    static __device__ __forceinline__ double match(double pe, double sum, double init, double c_begin) {
+        return __dmul_rn(pe, __fma_rn(init, c_begin, sum));
+    }
+    // Del level input p_MD m + p_ID i
+    static __device__ __forceinline__ double lv(const LinParams &lp, double m, double i) {
+        return __fma_rn(lp.p_ID, i, __dmul_rn(lp.p_MD, m));
+    }
+    static __device__ __forceinline__ double c_begin(const LinParams &lp, bool first, double ibs) {
+        return first ? lp.p_MM : __dmul_rn(lp.p_IM, ibs);
+    }
+    static __device__ __forceinline__ double ib_cur(const LinParams &lp, bool first, double ibs) {
+        return first ? __dmul_rn(lp.p_random, lp.p_MI) : __dmul_rn(__dmul_rn(lp.p_random, lp.p_II), ibs);
+    }
+    static __device__ __forceinline__ double log_end(const LinParams &lp, double stot, int E) {
+        return __fma_rn((double)E, SP_LN2, log(__dmul_rn(lp.p_end, stot)));
+    }
+};
+
 __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
     constexpr int CAP = 64;
     __shared__ HintedLeanShared sh;
@@ -178,12 +206,12 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
         // ---- fm, fi (forward.rs:337-388), fib (541-545)
         // (InsBegin of the previous column in that column's scale, fib forward.rs:541-545: carried along with the
         // exact power-of-two rescales instead of exp(logib[pos-1] - E ln 2) per position)
-        const double c_begin = first ? lp.p_MM : lp.p_IM * ibs;
-        const double ib_cur = first ? lp.p_random * lp.p_MI : lp.p_random * lp.p_II * ibs;
-        const double c_del = lp.p_ID * ib_cur;
+        const double c_begin = HStep::c_begin(lp, first, ibs);
+        const double ib_cur = HStep::ib_cur(lp, first, ibs);
+        const double c_del = __dmul_rn(lp.p_ID, ib_cur);
         const bool hadp = lane < n_prev;
-        const double G = hadp ? lp.p_MM * pm + lp.p_IM * pi + lp.p_DM * pd : 0.0;
-        const double H = hadp ? lp.p_MI * pm + lp.p_II * pi + lp.p_DI * pd : 0.0;
+        const double G = hadp ? HStep::lin3(lp.p_MM, pm, lp.p_IM, pi, lp.p_DM, pd) : 0.0;
+        const double H = hadp ? HStep::lin3(lp.p_MI, pm, lp.p_II, pi, lp.p_DI, pd) : 0.0;
         int ps[ADJ_DEG], cs[ADJ_DEG];
         uint32_t anyq = 0;  // wave-uniform: some lane has a q-th parent (on a DBG mostly q = 0 only)
 #pragma unroll
@@ -203,30 +231,30 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
         for (int q = 0; q < ADJ_DEG; q++) {
             if (!(anyq & (1u << q))) continue;
             const double v = hl_shfl(G, ps[q]);
-            if (ps[q] >= 0) acc += w_cur[q] * v;
+            if (ps[q] >= 0) acc = HStep::acc(w_cur[q], v, acc);
         }
         const double hv = hl_shfl(H, os);
         m = ii = d = 0.0;
         if (has) {
             const double pe = rc_cur.emis == x_cur ? lp.p_match : lp.p_mismatch;
-            m = pe * (acc + in_cur * c_begin);
-            ii = os >= 0 ? lp.p_random * hv : 0.0;
+            m = HStep::match(pe, acc, in_cur, c_begin);
+            ii = os >= 0 ? __dmul_rn(lp.p_random, hv) : 0.0;
         }
         HPROF(3)
         // ---- fd0 + n_max_gaps x fdt restricted to the list (forward.rs:423-524)
-        double lv = lp.p_MD * m + lp.p_ID * ii;
+        double lv = HStep::lv(lp, m, ii);
         for (int t = 0; t <= lp.n_max_gaps; t++) {
             double sacc = 0.0;
 #pragma unroll
             for (int q = 0; q < ADJ_DEG; q++) {
                 if (!(anyq & (1u << q))) continue;
                 const double v = hl_shfl(lv, cs[q]);
-                if (cs[q] >= 0) sacc += w_cur[q] * v;
+                if (cs[q] >= 0) sacc = HStep::acc(w_cur[q], v, sacc);
             }
-            if (t == 0) sacc += in_cur * c_del;
-            else sacc *= lp.p_DD;
+            if (t == 0) sacc = __fma_rn(in_cur, c_del, sacc);
+            else sacc = __dmul_rn(sacc, lp.p_DD);
             sacc = has ? sacc : 0.0;
-            d += sacc;
+            d = __dadd_rn(d, sacc);
             lv = sacc;
         }
         HPROF(4)
@@ -234,11 +262,11 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
         const double mx = wave_max(fmax(has ? fmax(fmax(m, ii), d) : 0.0, ib_cur));
         const int e = sp_exp_of(mx);
         const double sc = sp_pow2(-e);
-        m *= sc;
-        ii *= sc;
-        d *= sc;
+        m = __dmul_rn(m, sc);
+        ii = __dmul_rn(ii, sc);
+        d = __dmul_rn(d, sc);
         const int Ecur = (first ? 0 : Eprev) + e;
-        ibs = ib_cur * sc;
+        ibs = __dmul_rn(ib_cur, sc);
         if (a.pool.base && cand == 0) {
             // forward record of the position (every entry carries m, i and d)
             const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
@@ -292,8 +320,8 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
 #endif
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
     // fe (forward.rs:554-558) of the last column
-    const double stot = wave_sum(lane < n_prev ? pm + pi + pd : 0.0);
-    const double lpv = err ? NAN : log(lp.p_end * stot) + (double)Eprev * SP_LN2;
+    const double stot = wave_sum(lane < n_prev ? __dadd_rn(__dadd_rn(pm, pi), pd) : 0.0);
+    const double lpv = err ? NAN : HStep::log_end(lp, stot, Eprev);
     if (lane == 0) {
         a.out_logp[(size_t)cand * a.R + rd] = lpv;
         a.err[(size_t)cand * a.R + rd] = err;
@@ -341,18 +369,27 @@ template <int WG> __device__ __forceinline__ double group_sum(double v, int slot
     return __shfl(v, WG - 1, WG);
 }
 
-template <int WG>
+template <int WG, int CPL>
 __global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, const uint32_t n_cand) {
+    // CPL candidates per lane on top of the G = 64 / WG candidate groups of a wave: the topology work of a position
+    // (list, records, hash, lookups: ~100 VALU wave-instructions) is shared by G x CPL candidates, whose own work
+    // (~70 each: weights, G / H, shuffles, Del levels, rescale) runs CPL times per lane.
     constexpr int G = 64 / WG;
     __shared__ HintedLeanShared sh;
     const int lane = threadIdx.x;
     const int slot = lane % WG, grp = lane / WG, gbase = grp * WG;
     const uint32_t rd = a.read_ids[blockIdx.x];
-    uint32_t cand = blockIdx.y * G + (uint32_t)grp;
-    const bool cand_ok = cand < n_cand;
-    if (!cand_ok) cand = n_cand - 1;  // (idle groups of the last wave compute a copy; nothing is written)
-    const double *init = a.init_c + (size_t)cand * a.M.N;
-    const double *trans = a.trans_c + (size_t)cand * a.E;
+    uint32_t cand[CPL];
+    bool cand_ok[CPL];
+    const double *init[CPL], *trans[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        cand[c] = (blockIdx.y * G + (uint32_t)grp) * CPL + c;
+        cand_ok[c] = cand[c] < n_cand;
+        if (!cand_ok[c]) cand[c] = n_cand - 1;  // (idle slots of the last wave compute a copy; nothing is written)
+        init[c] = a.init_c + (size_t)cand[c] * a.M.N;
+        trans[c] = a.trans_c + (size_t)cand[c] * a.E;
+    }
     const ParRec *prec = a.M.prec;
     const LinParams &lp = a.M.lp;
     const uint64_t b0 = a.read_off[rd];
@@ -364,13 +401,22 @@ __global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, c
     uint32_t id_cur = (slot < n_cur && n_cur <= WG) ? a.map_nodes[o_cur + slot] : 0u;
     uint32_t id_nx = (slot < n_nx && n_nx <= WG) ? a.map_nodes[o_nx + slot] : 0u;
     ParRec rc_cur = prec[id_cur];
-    double in_cur = init[id_cur];
-    double w_cur[ADJ_DEG];
+    double in_cur[CPL], w_cur[CPL][ADJ_DEG];
 #pragma unroll
-    for (int q = 0; q < ADJ_DEG; q++) w_cur[q] = q < (int)rc_cur.npar ? trans[rc_cur.pedge[q]] : 0.0;
+    for (int c = 0; c < CPL; c++) {
+        in_cur[c] = init[c][id_cur];
+#pragma unroll
+        for (int q = 0; q < ADJ_DEG; q++) w_cur[c][q] = q < (int)rc_cur.npar ? trans[c][rc_cur.pedge[q]] : 0.0;
+    }
     uint8_t x_cur = a.bases[b0], x_nx = len >= 2 ? a.bases[b0 + 1] : (uint8_t)0;
-    double pm = 0.0, pi = 0.0, pd = 0.0, m = 0.0, ii = 0.0, d = 0.0, ibs = 0.0;
-    int Eprev = 0, n_prev = 0;
+    double pm[CPL], pi[CPL], pd[CPL], ibs[CPL];
+    int Eprev[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        pm[c] = pi[c] = pd[c] = ibs[c] = 0.0;
+        Eprev[c] = 0;
+    }
+    int n_prev = 0;
     for (int pos = 0; pos < len; pos++) {
         if (n_cur > WG) {
             err |= SP_ERR_CAPACITY;
@@ -378,7 +424,9 @@ __global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, c
         }
         // ---- requests for the positions ahead
         const ParRec rc_nx = prec[id_nx];
-        const double in_nx = init[id_nx];
+        double in_nx[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) in_nx[c] = init[c][id_nx];
         const uint64_t o_n3 = po[pos + 3 <= len ? pos + 3 : len];
         const int n_n2 = pos + 2 < len ? (int)(o_n3 - o_n2) : 0;
         const uint32_t id_n2 = (slot < n_n2 && n_n2 <= WG) ? a.map_nodes[o_n2 + slot] : 0u;
@@ -405,13 +453,9 @@ __global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, c
             hc[h].y = (uint32_t)slot;
         }
         wave_sync();
-        // ---- fm, fi (forward.rs:337-388), fib (541-545)
-        const double c_begin = first ? lp.p_MM : lp.p_IM * ibs;
-        const double ib_cur = first ? lp.p_random * lp.p_MI : lp.p_random * lp.p_II * ibs;
-        const double c_del = lp.p_ID * ib_cur;
+        // ---- the topology of the position, once for every candidate of the wave: lanes of the in-list parents in the
+        // previous (ps) and the current (cs) list, own lane in the previous list (os)
         const bool hadp = slot < n_prev;
-        const double Gv = hadp ? lp.p_MM * pm + lp.p_IM * pi + lp.p_DM * pd : 0.0;
-        const double Hv = hadp ? lp.p_MI * pm + lp.p_II * pi + lp.p_DI * pd : 0.0;
         int ps[ADJ_DEG], cs[ADJ_DEG];
         uint32_t anyq = 0;  // wave-uniform: some lane has a q-th parent (on a DBG mostly q = 0 only)
 #pragma unroll
@@ -427,53 +471,100 @@ __global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, c
             }
         }
         const int os = (has && !first) ? hl_find(hp, id_cur) : -1;
-        double acc = 0.0;
+        const double pe = rc_cur.emis == x_cur ? lp.p_match : lp.p_mismatch;
+        // byte addresses of the shuffles (ds_bpermute), once for all candidates of the lane
+        int aps[ADJ_DEG], acs[ADJ_DEG];
 #pragma unroll
         for (int q = 0; q < ADJ_DEG; q++) {
-            if (!(anyq & (1u << q))) continue;
-            const double v = __shfl(Gv, gbase + (ps[q] < 0 ? 0 : ps[q]));
-            if (ps[q] >= 0 && w_cur[q] != 0.0) acc += w_cur[q] * v;
+            aps[q] = (gbase + (ps[q] < 0 ? 0 : ps[q])) << 2;
+            acs[q] = (gbase + (cs[q] < 0 ? 0 : cs[q])) << 2;
         }
-        const double hv = __shfl(Hv, gbase + (os < 0 ? 0 : os));
-        m = ii = d = 0.0;
-        if (has) {
-            const double pe = rc_cur.emis == x_cur ? lp.p_match : lp.p_mismatch;
-            m = pe * (acc + in_cur * c_begin);
-            ii = os >= 0 ? lp.p_random * hv : 0.0;
-        }
-        // ---- fd0 + n_max_gaps x fdt restricted to the list (forward.rs:423-524)
-        double lv = lp.p_MD * m + lp.p_ID * ii;
-        for (int t = 0; t <= lp.n_max_gaps; t++) {
-            double sacc = 0.0;
+        const int aos = (gbase + (os < 0 ? 0 : os)) << 2;
+        auto pull = [](int addr, double v) -> double {
+            const long long b = __double_as_longlong(v);
+            const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(b & 0xffffffffll));
+            const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
+            return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+        };
+        // ---- per candidate: fm, fi (forward.rs:337-388), fib (541-545), fd0 + n_max_gaps x fdt restricted to the list
+        // (forward.rs:423-524), rescale.  Branch-free: a parent that is not in the list (or whose edge has weight 0 for
+        // this candidate) enters with weight 0 -- fma(0, v, s) = s exactly, what skipping it gives.
 #pragma unroll
-            for (int q = 0; q < ADJ_DEG; q++) {
-                if (!(anyq & (1u << q))) continue;
-                const double v = __shfl(lv, gbase + (cs[q] < 0 ? 0 : cs[q]));
-                if (cs[q] >= 0 && w_cur[q] != 0.0) sacc += w_cur[q] * v;
+        for (int c = 0; c < CPL; c++) {
+            const double c_begin = HStep::c_begin(lp, first, ibs[c]);
+            const double ib_cur = HStep::ib_cur(lp, first, ibs[c]);
+            const double c_del = __dmul_rn(lp.p_ID, ib_cur);
+            const double Gv = hadp ? HStep::lin3(lp.p_MM, pm[c], lp.p_IM, pi[c], lp.p_DM, pd[c]) : 0.0;
+            const double Hv = hadp ? HStep::lin3(lp.p_MI, pm[c], lp.p_II, pi[c], lp.p_DI, pd[c]) : 0.0;
+            const double hv = pull(aos, Hv);
+            double m, ii, d = 0.0;
+            if (anyq <= 1u) {
+                // the common case on a DBG: at most one in-list parent per entry
+                const double wp = ps[0] >= 0 ? w_cur[c][0] : 0.0, wc = cs[0] >= 0 ? w_cur[c][0] : 0.0;
+                const double acc = HStep::acc(wp, pull(aps[0], Gv), 0.0);
+                m = has ? HStep::match(pe, acc, in_cur[c], c_begin) : 0.0;
+                ii = (has && os >= 0) ? __dmul_rn(lp.p_random, hv) : 0.0;
+                double lv = HStep::lv(lp, m, ii);
+                for (int t = 0; t <= lp.n_max_gaps; t++) {
+                    double sacc = HStep::acc(wc, pull(acs[0], lv), 0.0);
+                    sacc = t == 0 ? __fma_rn(in_cur[c], c_del, sacc) : __dmul_rn(sacc, lp.p_DD);
+                    sacc = has ? sacc : 0.0;
+                    d = __dadd_rn(d, sacc);
+                    lv = sacc;
+                }
+            } else {
+                double wp[ADJ_DEG], wc[ADJ_DEG];
+#pragma unroll
+                for (int q = 0; q < ADJ_DEG; q++) {
+                    wp[q] = ps[q] >= 0 ? w_cur[c][q] : 0.0;
+                    wc[q] = cs[q] >= 0 ? w_cur[c][q] : 0.0;
+                }
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < ADJ_DEG; q++)
+                    if (anyq & (1u << q)) acc = HStep::acc(wp[q], pull(aps[q], Gv), acc);
+                m = has ? HStep::match(pe, acc, in_cur[c], c_begin) : 0.0;
+                ii = (has && os >= 0) ? __dmul_rn(lp.p_random, hv) : 0.0;
+                double lv = HStep::lv(lp, m, ii);
+                for (int t = 0; t <= lp.n_max_gaps; t++) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < ADJ_DEG; q++)
+                        if (anyq & (1u << q)) sacc = HStep::acc(wc[q], pull(acs[q], lv), sacc);
+                    sacc = t == 0 ? __fma_rn(in_cur[c], c_del, sacc) : __dmul_rn(sacc, lp.p_DD);
+                    sacc = has ? sacc : 0.0;
+                    d = __dadd_rn(d, sacc);
+                    lv = sacc;
+                }
             }
-            if (t == 0) sacc += in_cur * c_del;
-            else sacc *= lp.p_DD;
-            sacc = has ? sacc : 0.0;
-            d += sacc;
-            lv = sacc;
+            // rescale so that the column maximum of THIS candidate is in [0.5, 1)
+            const double mx = group_max<WG>(fmax(fmax(fmax(m, ii), d), ib_cur));
+            const int e = sp_exp_of(mx);
+            const double sc = sp_pow2(-e);
+            pm[c] = __dmul_rn(m, sc);
+            pi[c] = __dmul_rn(ii, sc);
+            pd[c] = __dmul_rn(d, sc);
+            Eprev[c] = (first ? 0 : Eprev[c]) + e;
+            ibs[c] = __dmul_rn(ib_cur, sc);
         }
-        // ---- rescale so that the column maximum of THIS candidate is in [0.5, 1)
-        const double mx = group_max<WG>(fmax(has ? fmax(fmax(m, ii), d) : 0.0, ib_cur));
-        const int e = sp_exp_of(mx);
-        const double sc = sp_pow2(-e);
-        m *= sc;
-        ii *= sc;
-        d *= sc;
-        const int Ecur = (first ? 0 : Eprev) + e;
-        ibs = ib_cur * sc;
         // ---- the column becomes the previous one; weights of the next position (its record has arrived)
-        pm = m;
-        pi = ii;
-        pd = d;
-        Eprev = Ecur;
         n_prev = n;
+        {
+            // (edge weights only for parent slots some lane of the wave uses: mostly the first)
+            int npmax = (int)rc_nx.npar;
 #pragma unroll
-        for (int q = 0; q < ADJ_DEG; q++) w_cur[q] = q < (int)rc_nx.npar ? trans[rc_nx.pedge[q]] : 0.0;
+            for (int off = 32; off >= 1; off >>= 1) npmax = max(npmax, __shfl_xor(npmax, off));
+            npmax = __builtin_amdgcn_readfirstlane(npmax);
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+#pragma unroll
+                for (int q = 0; q < ADJ_DEG; q++) {
+                    if (q < npmax) w_cur[c][q] = q < (int)rc_nx.npar ? trans[c][rc_nx.pedge[q]] : 0.0;
+                    else w_cur[c][q] = 0.0;
+                }
+                in_cur[c] = in_nx[c];
+            }
+        }
         o_cur = o_nx;
         o_nx = o_n2;
         o_n2 = o_n3;
@@ -482,17 +573,19 @@ __global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, c
         id_cur = id_nx;
         id_nx = id_n2;
         rc_cur = rc_nx;
-        in_cur = in_nx;
         x_cur = x_nx;
         x_nx = x_n2;
     }
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
     // fe (forward.rs:554-558) of the last column, per candidate
-    const double stot = group_sum<WG>(slot < n_prev ? pm + pi + pd : 0.0, slot);
-    const double lpv = err ? NAN : log(lp.p_end * stot) + (double)Eprev * SP_LN2;
-    if (slot == 0 && cand_ok) {
-        a.out_logp[(size_t)cand * a.R + rd] = lpv;
-        a.err[(size_t)cand * a.R + rd] = err;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const double stot = group_sum<WG>(slot < n_prev ? __dadd_rn(__dadd_rn(pm[c], pi[c]), pd[c]) : 0.0, slot);
+        const double lpv = err ? NAN : HStep::log_end(lp, stot, Eprev[c]);
+        if (slot == 0 && cand_ok[c]) {
+            a.out_logp[(size_t)cand[c] * a.R + rd] = lpv;
+            a.err[(size_t)cand[c] * a.R + rd] = err;
+        }
     }
 }
 
@@ -702,9 +795,21 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
         if (pcls[c].empty()) continue;
         HIP_CHECK(hipMemcpyAsync(d_ids.p, pcls[c].data(), pcls[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         const unsigned nr = (unsigned)pcls[c].size();
-        if (c == 0) hipLaunchKernelGGL(hinted_packed_kernel<8>, dim3(nr, (n_cand + 7) / 8), dim3(64), 0, s, a, n_cand);
-        else if (c == 1) hipLaunchKernelGGL(hinted_packed_kernel<16>, dim3(nr, (n_cand + 3) / 4), dim3(64), 0, s, a, n_cand);
-        else hipLaunchKernelGGL(hinted_packed_kernel<32>, dim3(nr, (n_cand + 1) / 2), dim3(64), 0, s, a, n_cand);
+        // candidates per wave = (64 / WG) x CPL; two per lane once a batch fills such waves
+        const int cpl_env = std::getenv("PHMM_PACKED_CPL") ? std::atoi(std::getenv("PHMM_PACKED_CPL")) : 0;
+        const int G = c == 0 ? 8 : (c == 1 ? 4 : 2);
+        const int cpl = cpl_env > 0 ? cpl_env : (n_cand >= (uint32_t)(2 * G) ? 2 : 1);
+        const unsigned per_wave = (unsigned)(G * (cpl >= 2 ? 2 : 1));
+        const dim3 grid(nr, (n_cand + per_wave - 1) / per_wave);
+        if (cpl >= 2) {
+            if (c == 0) hipLaunchKernelGGL((hinted_packed_kernel<8, 2>), grid, dim3(64), 0, s, a, n_cand);
+            else if (c == 1) hipLaunchKernelGGL((hinted_packed_kernel<16, 2>), grid, dim3(64), 0, s, a, n_cand);
+            else hipLaunchKernelGGL((hinted_packed_kernel<32, 2>), grid, dim3(64), 0, s, a, n_cand);
+        } else {
+            if (c == 0) hipLaunchKernelGGL((hinted_packed_kernel<8, 1>), grid, dim3(64), 0, s, a, n_cand);
+            else if (c == 1) hipLaunchKernelGGL((hinted_packed_kernel<16, 1>), grid, dim3(64), 0, s, a, n_cand);
+            else hipLaunchKernelGGL((hinted_packed_kernel<32, 1>), grid, dim3(64), 0, s, a, n_cand);
+        }
         HIP_CHECK(hipGetLastError());
         st.launches[2]++;
         HIP_CHECK(hipMemcpyAsync(h_err.data(), d_err.p, h_err.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));

@@ -78,6 +78,44 @@ def test_candidate_batch(gpu_lib, oracle):
         assert np.all((np.isneginf(lp2) & np.isneginf(lp[2])) | (np.abs(lp2 - lp[2]) < 1e-12))
 
 
+@pytest.mark.parametrize("cpl", ["1", "2"])
+def test_candidate_batch_packed_kernels_all_widths(gpu_lib, oracle, cpl, monkeypatch):
+    """Candidate batches on reads whose longest lists fall in each packed class (<= 8, <= 16, <= 32 nodes) and beyond
+    (one-candidate kernels), one and two candidates per lane: every (candidate, read) equals the oracle's score and
+    has the bits of the one-candidate evaluation."""
+    monkeypatch.setenv("PHMM_PACKED_CPL", cpl)
+    arrays, sg, reads, om, _ = _setup(oracle, genome_len=500, n_reads=8, seed=13, read_len=60)
+    gm = D.PHMMModel(arrays)
+    rng = np.random.default_rng(2)
+    # lists of the oracle's dense run cut to a per-read width: 3, 8, 9, 16, 17, 32, 33, 70 nodes
+    widths = [3, 8, 9, 16, 17, 32, 33, 70]
+    pos_off, nodes = [0], []
+    for r, wd in zip(reads, widths):
+        mpp = om.run(r).to_mapping(wd)
+        for i in range(len(r)):
+            nodes.extend(mpp.nodes(i))
+            pos_off.append(len(nodes))
+    mp = (np.array(pos_off, dtype=np.uint64), np.array(nodes, dtype=np.uint32), np.zeros(len(nodes)))
+    rc = D.ReadCollection(reads)
+    gmp = D.Mappings.from_arrays(rc, *mp)
+    C = 19
+    cns = []
+    for c in range(C):
+        cn = sg.copy_num.copy()
+        flip = rng.integers(0, cn.shape[0], size=12)
+        cn[flip] = rng.integers(0, 4, size=12)
+        cns.append(cn)
+    tot, lp = gm.to_full_prob_reads_copy_nums(rc, gmp, np.stack(cns), 0)
+    for c in (0, 7, 18):
+        t1, lp1 = gm.to_full_prob_reads_copy_nums(rc, gmp, np.stack(cns[c:c + 1]), 0)
+        assert np.array_equal(lp1[0], lp[c])
+        with np.errstate(divide="ignore"):
+            a2 = D.vectorised_to_phmm(D.SeqGraph(cns[c], sg.base, sg.edge_src, sg.edge_dst, None), arrays.param, 0)
+        ol = oracle.Model(a2).full_prob_reads(reads, mp, True, n_threads=8)
+        with np.errstate(invalid="ignore"):
+            assert np.all((np.isneginf(ol) & np.isneginf(lp[c])) | (np.abs(ol - lp[c]) < TOL_LOGP))
+
+
 def test_candidate_copy_numbers_on_device(gpu_lib, oracle):
     """candidates as copy-number vectors: init / trans built on the device (seq_graph.rs:160-209) give the
     same likelihoods as the host-built probability vectors, for to_phmm (min 0) and to_non_zero_phmm (min 1)."""
