@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <type_traits>
 
 #include "dense_internal.h"
 
@@ -36,6 +37,11 @@
 #endif
 #ifndef PHMM_BWD_PF
 #define PHMM_BWD_PF 1
+#endif
+// W < 64 instantiations (small read sets, plans of a few deferred reads): their launches do not fill the chip anyway, and
+// at 4 waves per SIMD fwd_step<16> spills 19 VGPRs into its row loop (31 -> 27 us per cfg2 launch without them)
+#ifndef PHMM_SMALLW_WAVES
+#define PHMM_SMALLW_WAVES 3
 #endif
 
 namespace phmm {
@@ -121,8 +127,23 @@ __device__ __forceinline__ double block_reduce_rows(double v, Op op, double *lds
     }
     return out;
 }
-// Sum over the W lanes that share one node (contiguous lane group); valid in every lane.
+// Sum over the W lanes that share one node (contiguous lane group); valid in lane r == 0 of the group (W = 16: in
+// every lane).  W = 16 is one DPP row: four row rotations (VALU moves) instead of four ds_bpermute round trips per
+// row of the run -- this sum sits in the row loop of bwd_step when node usage is wanted.
 template <int W> __device__ __forceinline__ double lanes_sum(double v) {
+    if (W == 16) {
+        auto ror = [](double x, auto ctrl) {
+            const long long b = __double_as_longlong(x);
+            const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), decltype(ctrl)::value, 0xf, 0xf, false);
+            const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), decltype(ctrl)::value, 0xf, 0xf, false);
+            return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+        };
+        v += ror(v, std::integral_constant<int, 0x128>());  // row_ror 8, 4, 2, 1
+        v += ror(v, std::integral_constant<int, 0x124>());
+        v += ror(v, std::integral_constant<int, 0x122>());
+        v += ror(v, std::integral_constant<int, 0x121>());
+        return v;
+    }
 #pragma unroll
     for (int off = 1; off < W; off <<= 1) v += __shfl_xor(v, off);
     return v;
@@ -139,7 +160,7 @@ struct OpAdd {
 // Launch `pos` (0..Lc): column pos of m,i for lanes with pos < len; d of column pos-1
 // for lanes with 1 <= pos <= len; the end sum of the last column for lanes with pos == len.
 template <int W, bool DMA>
-__global__ void __launch_bounds__(BLOCK, 4) fwd_step(const DenseArgs a, const int pos) {
+__global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) fwd_step(const DenseArgs a, const int pos) {
     __shared__ double lds[(BLOCK / 64) * 64];
     constexpr bool DMA_ = DMA && W == 64;
     // per wave: DMA_DEPTH slots of [m row 512 B][i row 512 B]
@@ -467,7 +488,7 @@ __device__ __forceinline__ void bwd_chain(const DenseArgs &a, int g, int p, doub
 static constexpr int BDMA_DEPTH = 3;      // rows in flight per wave (5 planes = 2.5 KB per row)
 static constexpr int BDMA_SLOT = 5 * 64;  // doubles per slot: [B' m][B' i][F m][F i][F d]
 template <int W, bool DMA>
-__global__ void __launch_bounds__(BLOCK, 4) bwd_step(const DenseArgs a, const int pos) {
+__global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) bwd_step(const DenseArgs a, const int pos) {
     __shared__ double lds[(BLOCK / 64) * 64];
     constexpr bool DMA_ = DMA && W == 64;
     __shared__ double ring[DMA_ ? (BLOCK / 64) * BDMA_DEPTH * BDMA_SLOT : 1];
