@@ -853,7 +853,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.err = (uint32_t *)(cp + o_err);
         ma.eoff = (unsigned long long *)(cp + o_eoff);
         ma.force_radix = std::getenv("PHMM_FORCE_RADIX") ? 1 : 0;
-        const bool st_on = W == 64;  // statistics of bwd_step<64> only (bench.py's roofline)
+        const bool st_on = W == 64 && mc.main_plan;  // statistics of the main plan's bwd_step<64> only (bench.py's roofline)
         LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock;
         if (mc.dense_token) dense_lock = std::unique_lock<std::mutex>(*mc.dense_token);

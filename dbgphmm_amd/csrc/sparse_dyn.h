@@ -178,6 +178,7 @@ struct MapChunk {
     double *cand_tot;
     int topk;  // > 0: to_mapping(topk) instead of to_mapping_by_score_ratio
     std::mutex *dense_token;  // held while the chunk runs its HBM-bound dense backward (sparse_dyn.hip)
+    bool main_plan;  // per-launch statistics (bench.py's roofline) cover the main plan's full-width launches only
 };
 
 // top_nodes(K) / the 400 best of a dense column (sparse_dyn.hip: select_top400).  The column is read through

@@ -436,7 +436,11 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             for (uint16_t h : reads->warm_hint) n_def += h >= warm_cols ? 1 : 0;
         }
         const uint64_t per_read = ((uint64_t)(prm.n_warmup + 2) * 24 + 4 * 8 + (uint64_t)map_planes * 8) * m->N;
-        limit_side = std::min<uint64_t>(limit_total / 8, n_def * per_read * 5 / 4);
+        // (lanes of that plan: its own read-group width pads a short list of reads up to a power of two)
+        uint64_t lanes_def = 1;
+        while (lanes_def < std::min<uint64_t>(n_def, 64)) lanes_def <<= 1;
+        if (n_def > 64) lanes_def = (n_def + 63) / 64 * 64;
+        limit_side = std::min<uint64_t>(limit_total / 8, lanes_def * per_read * 9 / 8);
     }
     const uint64_t limit_main = limit_total - limit_side;
 
@@ -464,15 +468,22 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             // dense column has somewhere to put its speculative next column)
             int Lc = (int)std::min<int64_t>((int64_t)pc->max_len, std::min<int64_t>(prm.n_warmup + 2, pc->lc_cap));
             if (pc->may_defer && g0 == 0 && n_workers == 1) {
-                // A main plan that misses one chunk by a little keeps a column or two less instead (a few more reads
-                // are deferred to the side plan, which runs beside it) -- a second chunk would add its whole
-                // latency-bound frontier phase to the critical path.
+                // The kept columns follow the memory: as many as ONE chunk of the whole plan affords, up to all
+                // n_warmup + 2 -- a small read set (a shard of a multi-GPU run) then defers nothing, and the side plan,
+                // a latency-bound chain of its own, cannot become the critical path.  A plan that misses one chunk
+                // at the default keeps a column or two less instead (a few more reads are deferred): a second chunk
+                // would add its whole frontier phase to the critical path.
                 auto cost = [&](int lc) { return (size_t)lc * NW * 24 + 4 * NW * 8 + (sink ? (size_t)map_planes * NW * 8 + (size_t)plan.nblk8 * BLOCK * 8 : 0); };
-                for (int cut = 0; cut <= 2 && Lc - cut >= 8; cut++)
-                    if ((uint64_t)plan.ng_total * cost(Lc - cut) <= limit) {
-                        Lc -= cut;
-                        break;
-                    }
+                // (two settings only, all columns or the default: anything in between would follow the small changes of
+                // the budget from call to call and re-allocate a quarter of a terabyte for one column more)
+                const int lc_full = (int)std::min<int64_t>((int64_t)pc->max_len, prm.n_warmup + 2);
+                if ((uint64_t)plan.ng_total * cost(lc_full) <= limit) Lc = lc_full;
+                else
+                    for (int cut = 0; cut <= 2 && Lc - cut >= 8; cut++)
+                        if ((uint64_t)plan.ng_total * cost(Lc - cut) <= limit) {
+                            Lc -= cut;
+                            break;
+                        }
             }
             // tables + (mapping flow) three emit-prob planes and the per-run maxima (mapping_flow.hip: pbuf)
             const size_t per_group = (size_t)Lc * NW * 24 + 4 * NW * 8 + (sink ? (size_t)map_planes * NW * 8 + (size_t)plan.nblk8 * BLOCK * 8 : 0);
@@ -548,6 +559,8 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         // staging on the device: the reads are resident (phmm_reads), the kernels want the bases
         // transposed to [group][pos][W] (dense: the Lc kept columns; sparse: the full length)
         trace("chunk setup");
+        if (std::getenv("PHMM_TRACE"))
+            std::fprintf(stderr, "      chunk: groups %d..%d of %d, W %d, kept columns %d, longest read %d\n", g0, g0 + ngc, plan.ng_total, W, Lc, Lfull);
         std::vector<int> hl((size_t)lanes, 0);
         uint64_t dense_cells = 0;
         for (int gi = 0; gi < lanes; gi++) {
@@ -609,7 +622,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         // ---- dense warm-up with per-read switch decisions
         int pos = 0;
         // per-launch statistics (bench.py's roofline) cover the full-width instantiation fwd_step<64> only
-        const bool st_on = W == 64;
+        const bool st_on = W == 64 && (it.pc->may_defer || !by_ratio);  // (not the few-read plans beside the main one)
         LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock(dense_token, std::defer_lock);
         // (plans of deferred reads are a handful of lanes: they neither take nor wait for the token)
@@ -886,6 +899,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 mc.cand_node = wa.cand_node;
                 mc.cand_tot = wa.cand_tot;
                 mc.dense_token = use_token ? &dense_token : nullptr;
+                mc.main_plan = it.pc->may_defer || !by_ratio;
                 trace("sparse forward");
                 mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
                 trace("mapping backward total");
@@ -915,6 +929,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             mc.cand_node = wa.cand_node;
             mc.cand_tot = wa.cand_tot;
                 mc.dense_token = use_token ? &dense_token : nullptr;
+                mc.main_plan = it.pc->may_defer || !by_ratio;
             mapping_backward_chunk(mc, sparse_lanes, sink, plan, g0, R);
         }
         for (int gi = 0; gi < lanes; gi++) {
