@@ -512,6 +512,19 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) bwd_
 
     if (lb == 0 && pos + 1 < a.Lc) bwd_chain<W>(a, g, pos + 1, lds);
 
+    // A block none of whose lanes has this column (a read group past its last dense backward column: groups are
+    // sorted by their reads' switch positions, so whole groups go quiet at the high columns) leaves its zero partial
+    // sums and is done; without this it walked its run of rows for nothing.
+    if (!__syncthreads_or(live)) {
+        if (threadIdx.x < W && lb < a.nblk) {
+            double *bp = a.bpart + ((size_t)(pos & 1) * a.ng + g) * a.nblk8 * W * 2;
+            bp[((size_t)lb * W + r) * 2 + 0] = 0.0;
+            bp[((size_t)lb * W + r) * 2 + 1] = 0.0;
+        }
+        if (a.want_map && a.Prun) a.Prun[((size_t)g * a.nblk8 + lb) * BLOCK + threadIdx.x] = 0.0;
+        return;
+    }
+
     int Epos = 0;
     double sc = 1.0;
     if (live && !first) {
