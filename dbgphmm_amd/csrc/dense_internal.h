@@ -28,7 +28,7 @@ struct DenseArgs {
     const uint32_t *fh_off, *bh_off;
     const HopEntry *fh, *bh;
     int hop_mode;
-    double cD[CHAIN_HOPS], cT[CHAIN_HOPS], cQ[CHAIN_HOPS];
+    const double *coef;  // [3][CHAIN_HOPS] cD, cT, cQ on the device (n_max_gaps != 4; the default uses Horner's rule in p_DD)
     LinParams lp;
     const double *logib;  // [Lc] forward InsBegin chain (log)
     // read batch
