@@ -224,11 +224,11 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) fwd_
         // m, i loads -- 16 B read + 24 B written per cell, no closure traffic at all.
         constexpr int H = CHAIN_HOPS;
         const int kbase = lb * (a.npt * ROWS) + row * a.npt;
-        double wg[H];  // g = p_MD m + p_ID i of nodes k-1 .. k-H (prev column, rescaled)
+        // partial sums D_j = sum_{h < j} p_DD^h A[h] over the per-hop sums A[h] of g = p_MD m + p_ID i at the ancestors
+        // h+1 hops up (prev column, rescaled), and T = the D_{G+1} of the node before
+        double D1 = 0.0, D2 = 0.0, D3 = 0.0, D4 = 0.0, D5 = 0.0, Tk = 0.0;
         double wm0 = 0.0, wi0 = 0.0;
         int nvalid = 0;
-#pragma unroll
-        for (int h = 0; h < H; h++) wg[h] = 0.0;
         const double c = lp.p_ID * ibs;  // p_MD*mb + p_ID*ib with mb = 0 (fmb)
         const double cb = lp.p_IM * ibs;
         // software pipeline: a ring of PF own-value loads stays in flight -- node k+PF is requested
@@ -315,7 +315,9 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) fwd_
                 double m1, i1, dacc, tacc;
                 if (a.hop_mode) {
                     if (!((nr.flags & CHAIN_F) && nvalid)) {
-                        // first node of the run, behind a branch, or a merge: rebuild the per-hop sums
+                        // first node of the run, behind a branch, or a merge: the per-hop sums A[h] of the ancestors
+                        // from the hop entries, folded into the partial sums D_j = sum_{h < j} p_DD^h A[h]
+                        double wg[H];
 #pragma unroll
                         for (int h = 0; h < H; h++) wg[h] = 0.0;
                         wm0 = wi0 = 0.0;
@@ -334,25 +336,27 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) fwd_
                                 wi0 += en.w * vi;
                             }
                         }
+                        const double q = lp.p_DD;
+                        D1 = wg[0];
+                        D2 = wg[0] + q * wg[1];
+                        D3 = wg[0] + q * (wg[1] + q * wg[2]);
+                        D4 = wg[0] + q * (wg[1] + q * (wg[2] + q * wg[3]));
+                        D5 = wg[0] + q * (wg[1] + q * (wg[2] + q * (wg[3] + q * wg[4])));
+                        // T = sum_{1 <= h <= G+1} p_DD^(h-1) A[h]: what the node before this one would have had as
+                        // its D_{G+1} if the window had just slid
+                        Tk = 0.0;
+#pragma unroll
+                        for (int h = H - 1; h >= 1; h--)
+                            if (h <= lp.n_max_gaps + 1) Tk = wg[h] + q * Tk;
                         nvalid = 1;
                     }
                     m1 = wm0;
                     i1 = wi0;
-                    if (lp.n_max_gaps == 4) {
-                        // the coefficients are powers of p_DD (fill_model_args): Horner's rule needs the one scalar
-                        // instead of twelve -- the kernel spills SGPRs into VGPR lanes otherwise (v_readlane in
-                        // the row loop) -- and a third fewer multiply-adds
-                        const double q = lp.p_DD;
-                        dacc = wg[0] + q * (wg[1] + q * (wg[2] + q * (wg[3] + q * wg[4])));
-                        tacc = wg[1] + q * (wg[2] + q * (wg[3] + q * (wg[4] + q * wg[5])));
-                    } else {
-                        dacc = tacc = 0.0;
-#pragma unroll
-                        for (int h = 0; h < H; h++) {
-                            dacc += a.coef[h] * wg[h];
-                            tacc += a.coef[H + h] * wg[h];
-                        }
-                    }
+                    // d-closure sum = D_{G+1}, its one-hop-shifted twin = the D_{G+1} of the node before (forward.rs:423-524
+                    // unrolled: sum_{h <= G} p_DD^h A[h] and sum_{1 <= h <= G+1} p_DD^(h-1) A[h])
+                    const int G = lp.n_max_gaps;
+                    dacc = G == 4 ? D5 : (G == 3 ? D4 : (G == 2 ? D3 : (G == 1 ? D2 : D1)));
+                    tacc = Tk;
                 } else {
                     m1 = i1 = dacc = tacc = 0.0;
                     const uint32_t o0 = a.fc_off[k], o1 = a.fc_off[k + 1];
@@ -387,10 +391,18 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) fwd_
                         }
                     }
                 }
-                // slide the window: this node becomes "k-1" of the next one
-#pragma unroll
-                for (int h = H - 1; h >= 1; h--) wg[h] = wg[h - 1];
-                wg[0] = lp.p_MD * om + lp.p_ID * oi;
+                // Slide: this node becomes "k-1" of the next one.  The window of per-hop sums shifts by one hop with
+                // this node's own g in front, so the partial sums obey D_j' = g + p_DD D_{j-1}: four multiply-adds in
+                // place, no window registers to move, no polynomial to re-evaluate.
+                {
+                    const double gk = lp.p_MD * om + lp.p_ID * oi, q = lp.p_DD;
+                    Tk = dacc;
+                    D5 = gk + q * D4;
+                    D4 = gk + q * D3;
+                    D3 = gk + q * D2;
+                    D2 = gk + q * D1;
+                    D1 = gk;
+                }
                 wm0 = om;
                 wi0 = oi;
             }
@@ -584,10 +596,10 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) bwd_
         // h[u] = e_u(x) m'[u], q[u] = p_r i'[u] come from a register window fed by own loads.
         constexpr int H = CHAIN_HOPS;
         const int kbase = lb * (a.npt * ROWS) + row * a.npt;
-        double wh[H], wq[H];  // h, q of nodes v+1 .. v+H (column pos+1, rescaled)
+        // partial sums over the per-hop sums of h, q at the descendants (column pos+1, rescaled): E_j = sum_{h < j}
+        // p_DD^h Hs[h], Q_j likewise, TE = the E_{G+1} of the node above
+        double E1 = 0.0, E2 = 0.0, E3 = 0.0, E4 = 0.0, E5 = 0.0, Q1 = 0.0, Q2 = 0.0, Q3 = 0.0, Q4 = 0.0, Q5 = 0.0, TE = 0.0;
         int nvalid = 0;
-#pragma unroll
-        for (int h = 0; h < H; h++) wh[h] = wq[h] = 0.0;
         // software pipeline: a ring of PFB rows (own B values of column pos+1 and the F column of the
         // posterior) stays in flight.  As in fwd_step the loads are unconditional (clamped rows, every
         // lane; pointers that a launch does not use alias a valid plane) and a ring slot is consumed before
@@ -686,7 +698,9 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) bwd_
                 double a1, ad, at, qd, qt;
                 if (a.hop_mode) {
                     if (!((nr.flags & CHAIN_B) && nvalid)) {
-                        // first node of the run, in front of a merge, or a branch node: rebuild the per-hop sums
+                        // first node of the run, in front of a merge, or a branch node: the per-hop sums of the
+                        // descendants from the hop entries, folded into E_j = sum_{h < j} p_DD^h Hs[h], Q_j likewise
+                        double wh[H], wq[H];
 #pragma unroll
                         for (int h = 0; h < H; h++) wh[h] = wq[h] = 0.0;
                         const uint32_t o0 = a.bh_off[v], o1 = a.bh_off[v + 1];
@@ -705,26 +719,31 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) bwd_
                                     wq[h] += qv;
                                 }
                         }
+                        const double q = lp.p_DD;
+                        E1 = wh[0];
+                        E2 = wh[0] + q * wh[1];
+                        E3 = wh[0] + q * (wh[1] + q * wh[2]);
+                        E4 = wh[0] + q * (wh[1] + q * (wh[2] + q * wh[3]));
+                        E5 = wh[0] + q * (wh[1] + q * (wh[2] + q * (wh[3] + q * wh[4])));
+                        Q1 = wq[0];
+                        Q2 = wq[0] + q * wq[1];
+                        Q3 = wq[0] + q * (wq[1] + q * wq[2]);
+                        Q4 = wq[0] + q * (wq[1] + q * (wq[2] + q * wq[3]));
+                        Q5 = wq[0] + q * (wq[1] + q * (wq[2] + q * (wq[3] + q * wq[4])));
+                        TE = 0.0;
+#pragma unroll
+                        for (int h = H - 1; h >= 1; h--)
+                            if (h <= lp.n_max_gaps + 1) TE = wh[h] + q * TE;
                         nvalid = 1;
                     }
-                    a1 = wh[0];
-                    if (lp.n_max_gaps == 4) {
-                        // (Horner in p_DD, see fwd_step: one scalar instead of eighteen, 13 operations instead of 24)
-                        const double q = lp.p_DD;
-                        ad = wh[0] + q * (wh[1] + q * (wh[2] + q * (wh[3] + q * wh[4])));
-                        at = wh[1] + q * (wh[2] + q * (wh[3] + q * (wh[4] + q * wh[5])));
-                        qt = wq[0] + q * (wq[1] + q * (wq[2] + q * (wq[3] + q * wq[4])));
-                        qd = q * (wq[0] + q * (wq[1] + q * (wq[2] + q * wq[3])));
-                    } else {
-                        ad = at = qd = qt = 0.0;
-#pragma unroll
-                        for (int h = 0; h < H; h++) {
-                            ad += a.coef[h] * wh[h];
-                            at += a.coef[H + h] * wh[h];
-                            qd += a.coef[2 * H + h] * wq[h];
-                            qt += a.coef[h] * wq[h];
-                        }
-                    }
+                    // a1 = the one-hop sum; ad = sum_{h <= G} p_DD^h Hs[h] = E_{G+1}; at = its one-hop-shifted twin =
+                    // the E_{G+1} of the node above; qt = Q_{G+1}; qd = p_DD Q_G   (backward.rs:299-483 unrolled)
+                    const int G = lp.n_max_gaps;
+                    a1 = E1;
+                    ad = G == 4 ? E5 : (G == 3 ? E4 : (G == 2 ? E3 : (G == 1 ? E2 : E1)));
+                    at = TE;
+                    qt = G == 4 ? Q5 : (G == 3 ? Q4 : (G == 2 ? Q3 : (G == 1 ? Q2 : Q1)));
+                    qd = lp.p_DD * (G == 4 ? Q4 : (G == 3 ? Q3 : (G == 2 ? Q2 : (G == 1 ? Q1 : 0.0))));
                 } else {
                     a1 = ad = at = qd = qt = 0.0;
                     const uint32_t o0 = a.bc_off[v], o1 = a.bc_off[v + 1];
@@ -742,14 +761,22 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) bwd_
                         qt += en.cAd * qq;
                     }
                 }
-                // slide the window: this node becomes "v+1" of the next (lower) one
-#pragma unroll
-                for (int h = H - 1; h >= 1; h--) {
-                    wh[h] = wh[h - 1];
-                    wq[h] = wq[h - 1];
+                // slide: this node becomes "v+1" of the next (lower) one -- E_j' = h + p_DD E_{j-1}, Q_j' = q + p_DD Q_{j-1}
+                // in place (see fwd_step)
+                if (a.hop_mode) {
+                    const double hk = ev * m0, q = lp.p_DD;
+                    TE = ad;
+                    E5 = hk + q * E4;
+                    E4 = hk + q * E3;
+                    E3 = hk + q * E2;
+                    E2 = hk + q * E1;
+                    E1 = hk;
+                    Q5 = q0 + q * Q4;
+                    Q4 = q0 + q * Q3;
+                    Q3 = q0 + q * Q2;
+                    Q2 = q0 + q * Q1;
+                    Q1 = q0;
                 }
-                wh[0] = ev * m0;
-                wq[0] = q0;
                 const double d = lp.p_DM * ad + lp.p_DI * (q0 + qd);
                 const double td = lp.p_DM * at + lp.p_DI * qt;
                 const double m = lp.p_MM * a1 + lp.p_MD * td + lp.p_MI * q0;
@@ -1243,23 +1270,8 @@ void fill_model_args(DenseArgs &a, const phmm_model *m) {
     a.fh = d.fh_ent.as<HopEntry>();
     a.bh_off = d.bh_off.as<uint32_t>();
     a.bh = d.bh_ent.as<HopEntry>();
-    {
-        const int G = m->lin.n_max_gaps;
-        a.hop_mode = G + 2 <= CHAIN_HOPS ? 1 : 0;
-        double pw[CHAIN_HOPS + 1];
-        pw[0] = 1.0;
-        for (int h = 1; h <= CHAIN_HOPS; h++) pw[h] = pw[h - 1] * m->lin.p_DD;
-        double cf[3 * CHAIN_HOPS];
-        for (int h = 0; h < CHAIN_HOPS; h++) {
-            cf[h] = h <= G ? pw[h] : 0.0;                                        // cD, hop h+1 <= G+1: p_DD^(hop-1)
-            cf[CHAIN_HOPS + h] = (h >= 1 && h <= G + 1) ? pw[h - 1] : 0.0;       // cT, 2 <= hop <= G+2: p_DD^(hop-2)
-            cf[2 * CHAIN_HOPS + h] = h + 1 <= G ? pw[h + 1] : 0.0;               // cQ, hop <= G: p_DD^hop
-        }
-        // (uploaded per call: three cache lines; the model's parameters may have been swapped since the last one)
-        const_cast<ModelDev &>(d).coef.upload(cf, sizeof(cf));
-        HIP_CHECK(hipStreamSynchronize(current_stream()));
-        a.coef = d.coef.as<double>();
-    }
+    // n_max_gaps <= 4: closure entries by hop + partial sums in p_DD (fwd_step / bwd_step); else merged closure entries
+    a.hop_mode = m->lin.n_max_gaps + 2 <= CHAIN_HOPS ? 1 : 0;
 }
 
 // forward InsBegin chain in the log domain: ib_0 = p_r*(p_MI*1 + p_II*0); ib_i = p_r*p_II*ib_{i-1}

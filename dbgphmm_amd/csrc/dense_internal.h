@@ -22,13 +22,13 @@ struct DenseArgs {
     const FwdEntry *fc;
     const uint32_t *bc_off;
     const BwdEntry *bc;
-    // n_max_gaps <= 4: closure entries by hop + per-thread windows (hop_mode = 1); coefficients of the
-    // per-hop sums A[h] (h = hop-1):  d-closure sum cD[h] A[h], its one-hop-shifted twin sum cT[h] A[h],
-    // and for the backward Ins terms sum cQ[h] Q[h]
+    // n_max_gaps <= 4: closure entries by hop (hop_mode = 1).  A thread keeps, for the node it is at, the partial sums
+    //   D_j = sum_{h < j} p_DD^h A[h]   over the per-hop sums A[h] (h = hop-1) of its ancestors (descendants):
+    // the d-closure sum is D_{G+1}, its one-hop-shifted twin the D_{G+1} of the node before, the backward Ins terms
+    // p_DD Q_G and Q_{G+1}; along a chain D_j' = own + p_DD D_{j-1}
     const uint32_t *fh_off, *bh_off;
     const HopEntry *fh, *bh;
     int hop_mode;
-    const double *coef;  // [3][CHAIN_HOPS] cD, cT, cQ on the device (n_max_gaps != 4; the default uses Horner's rule in p_DD)
     LinParams lp;
     const double *logib;  // [Lc] forward InsBegin chain (log)
     // read batch

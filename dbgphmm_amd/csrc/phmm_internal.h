@@ -221,7 +221,6 @@ struct ModelDev {
     DevBuf trans_lin;                 // f64[E] by edge id
     DevBuf fadj, badj;                // FwdAdj[N], BwdAdj[N]
     DevBuf prec;                      // ParRec[N]
-    DevBuf coef;                      // f64[3][CHAIN_HOPS]: Del-closure coefficients per hop (dense.hip)
     DevBuf logib;                     // f64[logib_len] forward InsBegin chain (log)
     size_t logib_len = 0;
     uint32_t max_degree = 0;
