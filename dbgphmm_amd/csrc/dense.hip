@@ -308,10 +308,7 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) fwd_
             }
             double mnew, inew = 0.0;
             const double pe = (uint8_t)nr.emis == x ? lp.p_match : lp.p_mismatch;
-            if (pos == 0) {
-                // f_init: mb = 1, everything else 0 (forward.rs:255-266)
-                mnew = pe * nr.init * lp.p_MM;
-            } else {
+            {   // (column 0 is fwd_init's: no branch on pos here -- the loop-carried state would be copied at its join)
                 double m1, i1, dacc, tacc;
                 if (a.hop_mode) {
                     if (!((nr.flags & CHAIN_F) && nvalid)) {
@@ -440,6 +437,41 @@ __global__ void __launch_bounds__(BLOCK, (W == 64 ? 4 : PHMM_SMALLW_WAVES)) fwd_
     }
     if (lb == 0 && threadIdx.x < W && (newcol || have_prev))
         a.FE[((size_t)g * (a.Lc + 1) + pos) * W + r] = Epos;
+}
+
+// Column 0 (f_init + the first f_step, forward.rs:255-306 with mb = 1 and everything else 0): m = e_k(x) init_k p_MM,
+// i = 0; the column maximum for launch 1's rescale; exponent 0.  Same thread -> node mapping as fwd_step.
+template <int W>
+__global__ void __launch_bounds__(BLOCK) fwd_init(const DenseArgs a) {
+    __shared__ double lds[(BLOCK / 64) * 64];
+    const int g = blockIdx.y + a.g_off;
+    const int lb = xcd_block(blockIdx.x, a.nblk8);
+    constexpr int ROWS = BLOCK / W;
+    const int r = threadIdx.x % W, row = threadIdx.x / W;
+    const int len = a.len[g * W + r];
+    const bool active = a.wf_sw == nullptr || a.wf_sw[g * W + r] < 0;
+    const bool newcol = active && 0 < len;
+    if (!__syncthreads_or(newcol)) return;
+    const size_t NW = (size_t)a.N * W;
+    double *cm_ = a.Fm + (size_t)g * a.Lc * NW, *ci_ = a.Fi + (size_t)g * a.Lc * NW;
+    const uint8_t x = newcol ? a.bases[(size_t)g * a.Lc * W + r] : (uint8_t)0;
+    double vmax = 0.0;
+    if (lb < a.nblk && newcol) {
+        const int kbase = lb * (a.npt * ROWS) + row * a.npt;
+        for (int j = 0; j < a.npt; j++) {
+            const int k = kbase + j;
+            if (k >= a.N) break;
+            const NodeRec nr = a.nodes[k];
+            const double mnew = ((uint8_t)nr.emis == x ? a.lp.p_match : a.lp.p_mismatch) * nr.init * a.lp.p_MM;
+            cm_[(size_t)k * W + r] = mnew;
+            ci_[(size_t)k * W + r] = 0.0;
+            vmax = fmax(vmax, mnew);
+        }
+    }
+    const double bm = block_reduce_rows<W>(vmax, OpMax(), lds);
+    if (threadIdx.x < W && newcol && lb < a.nblk)
+        atomicMax(&a.cmaxF[(size_t)g * a.Lc * W + r], (unsigned long long)__double_as_longlong(bm));
+    if (lb == 0 && threadIdx.x < W && newcol) a.FE[(size_t)g * (a.Lc + 1) * W + r] = 0;
 }
 
 // log P(read) = ln(p_end * sum_k (m+i+d)) of the last column (fe, forward.rs:554-558)
@@ -1005,7 +1037,8 @@ template <int W> static void launch_fwd_one(const DenseArgs &a0, int pos, int g_
         g_cnt = a.ng;
         s = current_stream();
     }
-    if (W == 64 && dma && a.npt % DMA_DEPTH == 0)
+    if (pos == 0) hipLaunchKernelGGL(fwd_init<W>, dim3(a.nblk8, g_cnt), dim3(BLOCK), 0, s, a);
+    else if (W == 64 && dma && a.npt % DMA_DEPTH == 0)
         hipLaunchKernelGGL((fwd_step<W, true>), dim3(a.nblk8, g_cnt), dim3(BLOCK), 0, s, a, pos);
     else
         hipLaunchKernelGGL((fwd_step<W, false>), dim3(a.nblk8, g_cnt), dim3(BLOCK), 0, s, a, pos);
