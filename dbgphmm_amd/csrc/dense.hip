@@ -1179,9 +1179,11 @@ void launch_chunk_w(phmm_model *m, int W, const DenseArgs &a, bool do_bwd, CallS
 // smallest width that holds it (a plan of 35 deferred reads as 9 groups of 4 ran its dense columns 2.5x slower than as
 // one group of 64: padding lanes cost next to nothing, per-lane node work does)
 int choose_width(uint64_t R) {
+    // (at most 32: the full-width instantiations then only ever run full-size plans, and their rocprof averages
+    // are not mixed with the one-group launches of the small plans beside them)
     if (R <= 64) {
         int W = 1;
-        while ((uint64_t)W < R) W <<= 1;
+        while ((uint64_t)W < R && W < 32) W <<= 1;
         return W;
     }
     for (int W = 64; W >= 2; W >>= 1) {
