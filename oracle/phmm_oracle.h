@@ -169,6 +169,9 @@ int orc_run_dense_reads(const orc_model *m, const orc_params *p, const uint8_t *
                         double *out_logp_forward, double *out_logp_backward,
                         double *out_node_freq);
 
+/* test hook: see phmm_oracle.c (tie order of the value sorts) */
+void orc_set_tie_rule(double eps, int reverse);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,23 +13,9 @@ import pytest
 
 import dbgphmm_amd as D
 from dbgphmm_amd import _ffi
-from helpers import compare_mappings, same_mappings
+from helpers import compare_mappings, same_mappings, subset_csr
 
 pytestmark = pytest.mark.gpu
-
-
-def _subset_csr(reads, offsets, arrays, idx):
-    """CSR triple of the reads `idx` cut out of the triple over all reads."""
-    po, nd, lp = arrays
-    out_off, nodes, logp = [0], [], []
-    for r in idx:
-        p0, p1 = int(offsets[r]), int(offsets[r + 1])
-        e0, e1 = int(po[p0]), int(po[p1])
-        nodes.append(nd[e0:e1])
-        logp.append(lp[e0:e1])
-        out_off.extend((po[p0 + 1:p1 + 1].astype(np.int64) - e0 + out_off[-1]).tolist())
-    return (np.array(out_off, dtype=np.uint64), np.concatenate(nodes) if nodes else np.zeros(0, np.uint32),
-            np.concatenate(logp) if logp else np.zeros(0))
 
 
 @pytest.fixture(scope="module")
@@ -68,7 +54,7 @@ def test_cfg3_sample_matches_oracle(cfg3, oracle):
     olp = om.full_prob_reads(sub, None, True, n_threads=16)
     glp = mp.read_logp()[1][sample]
     assert np.max(np.abs(glp - olp)) < 1e-6, (np.abs(glp - olp).max(), sample[np.argmax(np.abs(glp - olp))])
-    gsub = _subset_csr(reads, off, (po, nd, lp), sample)
+    gsub = subset_csr(off, (po, nd, lp), sample)
     compare_mappings(sub, gsub, omp)
     # node usage of the sampled reads (Mappings::to_node_freqs restricted to them)
     gnf = np.bincount(gsub[1], weights=np.exp(gsub[2]), minlength=arrays.n_nodes)
