@@ -50,11 +50,12 @@ def compare_mappings(reads, gpu_arrays, orc_arrays, min_logp=-20.0, tol=1e-6, to
             assert ka == kb, (i, gn, gl, on, ol)
             # (nodes with equal probability -- e.g. the two haplotype copies of a k-mer -- may swap)
             assert np.max(np.abs(gl[:ka] - ol[:kb]), initial=0.0) < tol, (i, gl, ol)
-            capped = a1 - a0 == 400 or b1 - b0 == 400
+            capped = a1 - a0 == 400 or b1 - b0 == 400 or (top_k and a1 - a0 == top_k)  # (a full fixed-size list too)
             if capped:
                 # list capped at MAX_ACTIVE_NODES: which of the nodes that TIE with the 400th value are
                 # kept is arbitrary (sparsevec tie order is unpinned); compare strictly above the cut
-                ka = kb = int((gl > gl[-1] + 1e-9).sum())
+                # (a fixed-size list goes on below any ratio: values are compared down to e^-30 of the best)
+                ka = kb = int((gl > max(gl[-1] + 1e-9, gl[0] - 30.0)).sum())
             assert sorted(gn[:ka].tolist()) == sorted(on[:kb].tolist()), (i, gn, on)
             od = dict(zip(on[:kb].tolist(), ol[:kb].tolist()))
             assert all(abs(od[n] - l) < tol for n, l in zip(gn[:ka].tolist(), gl[:ka].tolist())), (i, gn, gl, on, ol)
@@ -118,7 +119,7 @@ def subset_csr(offsets, arrays, idx):
 TIE_RULES = ((1e-9, 0), (1e-9, 1), (1e-6, 0), (1e-6, 1), (0.0, 1))
 
 
-def compare_mappings_tie_aware(oracle_mod, om, reads, gpu_arrays, orc_arrays, **kw):
+def compare_mappings_tie_aware(oracle_mod, om, reads, gpu_arrays, orc_arrays, use_max_ratio=True, **kw):
     """compare_mappings read by read; a read that fails is run again through the oracle with its value sorts
     breaking near-ties the other ways (orc_set_tie_rule: values within 1e-9 / 1e-6 of each other count as tied, in
     iteration order or reversed) and passes when the GPU lists equal the oracle's under one of them.  The
@@ -141,7 +142,7 @@ def compare_mappings_tie_aware(oracle_mod, om, reads, gpu_arrays, orc_arrays, **
         for eps, rev in TIE_RULES:
             L.orc_set_tie_rule(eps, rev)
             try:
-                o1, _ = om.generate_mappings([r], None, True, n_threads=1)
+                o1, _ = om.generate_mappings([r], None, use_max_ratio, n_threads=1)
                 compare_mappings([r], g1, o1, **kw)
                 break
             except AssertionError:
@@ -151,9 +152,33 @@ def compare_mappings_tie_aware(oracle_mod, om, reads, gpu_arrays, orc_arrays, **
         else:
             # a read that fills a 400-slot sparse vector of the reference (the overflow regime of DESIGN.md section 2:
             # the two restatements do not drop the same inserts) is outside the parity domain
-            f = om.forward(r, oracle_mod.FWD_SPARSE_RATIO)
+            f = om.forward(r, oracle_mod.FWD_SPARSE_RATIO if use_max_ratio else oracle_mod.FWD_SPARSE_TOPK)
             if max([len(f.nodes(i, w)) for i in range(len(r)) if not f.is_dense(i) for w in (0, 1, 2)], default=0) < 400:
                 raise first
             retried -= 1
             overflow += 1
     return retried, overflow
+
+
+def scores_tie_aware(oracle_mod, got, want, recompute, tol=1e-6):
+    """Per-read scores `got` against the oracle's `want`; a read off by more than tol is recomputed by
+    `recompute(read_index)` under the other tie rules (see compare_mappings_tie_aware) and must match one of them.
+    -> number of reads that needed another tie order."""
+    import ctypes as C
+    L = oracle_mod.lib()
+    L.orc_set_tie_rule.argtypes = [C.c_double, C.c_int]
+    bad = np.flatnonzero(~((np.abs(got - want) < tol) | ((got == want))))
+    for b in bad:
+        seen = [float(want[b])]
+        for eps, rev in TIE_RULES:
+            L.orc_set_tie_rule(eps, rev)
+            try:
+                v = recompute(int(b))
+            finally:
+                L.orc_set_tie_rule(0.0, 0)
+            seen.append(float(v))
+            if abs(v - got[b]) < tol or v == got[b]:
+                break
+        else:
+            raise AssertionError((int(b), float(got[b]), seen))
+    return int(bad.size)
