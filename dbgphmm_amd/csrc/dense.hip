@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "dense_internal.h"
+#include "lds_dma.h"
 
 #ifndef PHMM_FWD_PF
 #define PHMM_FWD_PF 2
@@ -69,18 +70,7 @@ __device__ __forceinline__ NodeRec load_node(const NodeRec *nodes, int k) {
     return r;
 }
 
-// ---- LDS-DMA row prefetch (fwd_step<64, true>) --------------------------------------------------------
-// global_load_lds_dwordx4: 16 bytes per lane straight into LDS (wave-uniform base in M0 + lane*16), no
-// VGPR held while the load is in flight -- the only way to keep several rows per wave in flight at 128
-// VGPRs.  Issued from inline asm so that hipcc does not count it; the matching s_waitcnt vmcnt(N) is placed
-// by hand (loads, stores and LDS-DMA retire in issue order on one counter).
-__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
+// ---- LDS-DMA row prefetch (fwd_step<64, true>): glds16, lds_dma.h ----------------------------------------
 // wait until at most n vector-memory operations of this wave are outstanding (n wave-uniform, 0..31)
 __device__ __forceinline__ void wait_vmcnt(int n) {
 #define PHMM_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;

@@ -1,5 +1,6 @@
-// Shared by the one-lane-per-node frontier kernels (lean_fwd_kernel.h, lean_bwd_kernel.h): an LDS
-// hash node -> lane for the <= 64 nodes resident on a wave, rebuilt once per read position.
+// Shared by the one-lane-per-node frontier kernels (lean_fwd_kernel.h, lean_bwd_kernel.h): constants, and the LDS
+// hash node -> lane of the backward kernel (rebuilt once per read position; the forward kernel keeps lane links
+// from position to position instead).
 #pragma once
 
 #include "sparse_dev.h"
@@ -12,8 +13,6 @@ static constexpr uint64_t LN_SLAB = 32768;  // record-pool bytes claimed per ato
 
 struct LeanShared {
     uint2 ent[LN_HASH];  // {node, lane}: one 8-byte LDS read answers a lookup
-    uint32_t winkey[64];  // insertion queue: new nodes and their hash cells
-    uint16_t winh[64];
 };
 
 __device__ __forceinline__ void ln_sync() { wave_sync(); }

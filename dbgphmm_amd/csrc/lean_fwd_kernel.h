@@ -1,5 +1,5 @@
 // The <= 64-node class of the adaptive sparse forward (phase B of sparse_fwd_kernel.h), one
-// wave64 per read, ONE LANE PER NODE.
+// wave64 per read, ONE LANE PER NODE, links kept across positions.
 //
 // Same recursion as fwd_adaptive_step (frontier_dev.h):
 //   top     = nodes of the previous column within the score ratio       table.rs:134-149
@@ -7,160 +7,196 @@
 //   m, i    over the active list                                        forward.rs:337-388
 //   d       = fd0 + n_max_gaps x fdt over S0 = children(active), S_t = children(S_{t-1})
 //                                                                       forward.rs:423-524
-// but laid out for the common case -- a frontier of 10-30 nodes walking along unitigs:
+// laid out for the common case -- a frontier of 10-30 nodes walking along unitigs:
 //   * a node owns a lane for as long as it stays in the frontier; its adjacency record (FwdAdj,
-//     96 B) and its previous-column values live in that lane's registers, so a step only touches
-//     memory for nodes that are new to the frontier (normally the deepest Del level: one round
-//     trip per step instead of ~25 dependent ones);
-//   * parents are reached by lane index (an LDS hash node -> lane rebuilt per step, resolved once
-//     per step) and their values by ds_bpermute, no loops over vector entries, no sorting:
-//     selection by ratio needs the set, not the order.
+//     96 B) and its previous-column values live in that lane's registers;
+//   * every lane knows the LANES of its node's parents and children (pl, cl).  The links are kept
+//     from position to position and only touched when a node enters or leaves the frontier: a node
+//     that enters announces its id by a lane read and every lane compares it with its own parent
+//     and child ids; the new lane finds its own neighbours by reading its record's ids lane by
+//     lane against the resident ids; a node that leaves is cut out of the links by its lane bit.
+//     A position normally takes in one node (the deepest Del level) and drops one, so this is a
+//     few dozen scalar-broadcast compares -- no LDS hash, no barriers, no scans;
+//   * values of parents are read by ds_bpermute; selection by ratio needs the set, not the order.
 // What the lane order changes: only the order of equal-probability entries inside a stored record
 // (the reference's own tie order is unpinned).  The class never drops an insert:
 // when previous + current nodes need more than 64 lanes it stops BEFORE storing the column and the
 // host continues in the 400-slot class, exactly like the generic <64> kernel.
 #pragma once
 
+#include "lds_dma.h"
 #include "lean_common.h"
 #include "sparse_fwd_kernel.h"
 
 namespace phmm {
 
+// Five lane numbers, one byte each (L2_NONE: no lane).
+struct L2Links {
+    uint32_t lo, hi;  // slots 0..3, slot 4
+};
+static constexpr uint32_t L2_NONE = 0xffu;
+template <int Q> __device__ __forceinline__ uint32_t l2_byte(const L2Links &k) {
+    return Q < 4 ? (k.lo >> (8 * Q)) & 0xffu : k.hi & 0xffu;
+}
+template <int Q> __device__ __forceinline__ void l2_put(L2Links &k, uint32_t v) {
+    if (Q < 4) k.lo = (k.lo & ~(0xffu << (8 * (Q & 3)))) | (v << (8 * (Q & 3)));
+    else k.hi = v;
+}
+
 struct LeanLane {
     uint32_t id;          // node on this lane (LN_EMPTY: free)
     FwdAdj r;             // its adjacency record
-    double pm, pi, pd;    // previous column (scaled), 0 for a node new to the frontier
-    double m, i, d;       // current column
-    int pl[ADJ_DEG];      // lanes of the parents (-1: not in the frontier)
-    bool miss;            // some child is not in the frontier
+    double pm, pi, pd;    // previous column (scaled), 0 on a free lane and for a node new to the frontier
+    double m, i, d;       // current column (0 on a free lane)
+    L2Links pl, cl;       // lanes of the parents / children
+    unsigned long long pmask;  // the parents' lanes as a bit set
+    int nres;             // children that are in the frontier (of r.nchi)
 };
 
-// Children of the nodes on the lanes of `src`: lanes that hold them are returned as a mask; children
-// that are not in the frontier yet take free lanes (their records are fetched).  Returns false when
-// the free lanes do not suffice (nothing is modified in that case except hash cells of the keys that
-// could not be placed -- the caller abandons the column).
-__device__ __forceinline__ void ln_links(const LeanShared &sh, LeanLane &L) {
-    // parents and children in one batch of lookups
-    uint32_t key[2 * ADJ_DEG];
-    bool valid[2 * ADJ_DEG];
-    int res[2 * ADJ_DEG];
+static_assert(sizeof(FwdAdj) == 96, "six 16-byte pieces are fetched ahead");
+
+// The record of the node the frontier is expected to take in next is requested a position ahead, straight into
+// LDS (no register, no wait until it is read).  On a unitig the node that enters is the first child of the one
+// that entered before it.
+struct LeanFwdShared {
+    uint32_t stage[32];  // 96 bytes used
+};
+
+// a wave-uniform double, told to the compiler (kept in scalar registers)
+__device__ __forceinline__ double l2_uniform(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// The lanes in `gone` leave the frontier: cut them out of everybody's links.
+__device__ __forceinline__ void l2_evict(LeanLane &L, unsigned long long gone) {
+    if ((gone >> threadIdx.x) & 1ull) {
+        L.id = LN_EMPTY;
+        L.pm = L.pi = L.pd = 0.0;
+    }
+    L.pmask &= ~gone;
+    for (unsigned long long gm = gone; gm != 0ull; gm &= gm - 1ull) {
+        const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane(__ffsll((long long)gm) - 1);
+#define L2_CUT(Q)                                       \
+    if (l2_byte<Q>(L.pl) == g) l2_put<Q>(L.pl, L2_NONE); \
+    if (l2_byte<Q>(L.cl) == g) {                         \
+        l2_put<Q>(L.cl, L2_NONE);                        \
+        L.nres--;                                        \
+    }
+        L2_CUT(0) L2_CUT(1) L2_CUT(2) L2_CUT(3) L2_CUT(4)
+#undef L2_CUT
+    }
+}
+
+// Node `key` (wave-uniform) takes the free lane `f` (wave-uniform): record, links in both directions.
+__device__ __forceinline__ void l2_adopt(const SparseModel &M, LeanFwdShared &sh, LeanLane &L, uint32_t &ahead, uint32_t key,
+                                         int f) {
+    const int lane = threadIdx.x;
+    const bool me = lane == f;
     const bool live = L.id != LN_EMPTY;
-#pragma unroll
-    for (int q = 0; q < ADJ_DEG; q++) {
-        key[q] = L.r.par[q];
-        valid[q] = live && q < (int)L.r.npar;
-        key[ADJ_DEG + q] = L.r.chi[q];
-        valid[ADJ_DEG + q] = live && q < (int)L.r.nchi;
+    // everybody's links TO the new node (needs its id only)
+#define L2_TONEW(Q)                                                   \
+    if (live && Q < (int)L.r.npar && L.r.par[Q] == key) {             \
+        l2_put<Q>(L.pl, (uint32_t)f);                                 \
+        L.pmask |= 1ull << f;                                         \
+    }                                                                 \
+    if (live && Q < (int)L.r.nchi && L.r.chi[Q] == key) {             \
+        l2_put<Q>(L.cl, (uint32_t)f);                                 \
+        L.nres++;                                                     \
     }
-    ln_find_many<2 * ADJ_DEG>(sh, key, valid, res);
-    bool miss = false;
-#pragma unroll
-    for (int q = 0; q < ADJ_DEG; q++) {
-        L.pl[q] = res[q];
-        miss |= valid[ADJ_DEG + q] && res[ADJ_DEG + q] < 0;
+    L2_TONEW(0) L2_TONEW(1) L2_TONEW(2) L2_TONEW(3) L2_TONEW(4)
+#undef L2_TONEW
+    // its record: requested a position ahead, or fetched now
+    if (key == ahead) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (me) L.r = *(const FwdAdj *)sh.stage;
+    } else if (me) {
+        L.r = M.fadj[key];
     }
-    L.miss = miss;
+    // (a free lane holds zeros: pm, pi, pd since it was freed, m, i, d since the step began)
+    if (me) L.id = key;
+    // the new node's own links: its parents and children among the resident nodes (itself included: a self loop)
+    const int np = __builtin_amdgcn_readlane((int)L.r.npar, f), nc = __builtin_amdgcn_readlane((int)L.r.nchi, f);
+    L2Links npl{0xffffffffu, L2_NONE}, ncl{0xffffffffu, L2_NONE};
+    unsigned long long npm = 0ull;
+    int nr = 0;
+#define L2_OWN(Q)                                                                              \
+    {                                                                                          \
+        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)L.r.par[Q], f);           \
+        const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)L.r.chi[Q], f);           \
+        const unsigned long long pmk = __ballot(Q < np && L.id == pk);                         \
+        const unsigned long long cmk = __ballot(Q < nc && L.id == ck);                         \
+        if (pmk != 0ull) {                                                                     \
+            const int pp = __ffsll((long long)pmk) - 1;                                        \
+            l2_put<Q>(npl, (uint32_t)pp);                                                      \
+            npm |= 1ull << pp;                                                                 \
+        }                                                                                      \
+        if (cmk != 0ull) {                                                                     \
+            l2_put<Q>(ncl, (uint32_t)(__ffsll((long long)cmk) - 1));                           \
+            nr++;                                                                              \
+        }                                                                                      \
+    }
+    L2_OWN(0) L2_OWN(1) L2_OWN(2) L2_OWN(3) L2_OWN(4)
+#undef L2_OWN
+    if (me) {
+        L.pl = npl;
+        L.cl = ncl;
+        L.pmask = npm;
+        L.nres = nr;
+    }
+    // request the record of its first child for the next position
+    if (nc > 0) {
+        ahead = (uint32_t)__builtin_amdgcn_readlane((int)L.r.chi[0], f);
+        if (lane < 6)
+            glds16((const uint8_t *)&M.fadj[ahead] + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)sh.stage));
+    }
 }
 
-// lanes that hold a child of a lane of `src` = resident nodes with a parent on a lane of `src`
-__device__ __forceinline__ unsigned long long ln_children_of(const LeanLane &L, unsigned long long src) {
-    bool hit = false;
-#pragma unroll
-    for (int q = 0; q < ADJ_DEG; q++) hit |= L.pl[q] >= 0 && ((src >> L.pl[q]) & 1ull);
-    return __ballot(hit);
+// Lanes of `src` with a child that is not in the frontier yet.
+__device__ __forceinline__ unsigned long long l2_need(const LeanLane &L, unsigned long long src) {
+    return __ballot(((src >> threadIdx.x) & 1ull) && L.id != LN_EMPTY && L.nres < (int)L.r.nchi);
 }
 
-// The insertion half of an expansion, kept out of line (inlined next to the fast path it doubles the
-// kernel's registers): children of the `insrc` lanes that are not in the frontier yet are queued and the
-// free lanes take them in order.  Returns the number of new nodes (-1: the free lanes do not suffice; only
-// hash cells of keys that could not be placed are modified then) and, per lane, the node it has to adopt.
-struct LnAdopt {
-    int total;
-    uint32_t key;  // LN_EMPTY: this lane adopts nothing
-};
-__device__ __noinline__ LnAdopt ln_insert_children(LeanShared &sh, bool insrc, bool occupied, uint32_t c0, uint32_t c1,
-                                                   uint32_t c2, uint32_t c3, uint32_t c4, int nchi) {
-    const int lane = threadIdx.x;
-    const uint32_t chi[ADJ_DEG] = {c0, c1, c2, c3, c4};
-    uint16_t hc[ADJ_DEG];
-    uint32_t wins = 0;
-#pragma unroll
-    for (int q = 0; q < ADJ_DEG; q++) {
-        hc[q] = 0;
-        if (insrc && q < nchi) {
-            const uint32_t key = chi[q];
-            uint32_t h = ln_hash(key);
-            for (;;) {
-                const uint32_t old = atomicCAS(&sh.ent[h].x, LN_EMPTY, key);
-                if (old == LN_EMPTY) {
-                    wins |= 1u << q;
-                    break;
-                }
-                if (old == key) break;
-                h = (h + 1) & (LN_HASH - 1);
-            }
-            hc[q] = (uint16_t)h;
-        }
-    }
-    // winners of new keys queue them; free lanes pick them up in order
-    const int nw = __popc(wins);
-    const int incl = wave_iscan(nw);
-    const int total = __shfl(incl, 63);
-    const unsigned long long freemask = ~__ballot(occupied);
-    LnAdopt r{total, LN_EMPTY};
-    if (total > __popcll(freemask)) {
-        r.total = -1;
-        return r;
-    }
-    if (total > 0) {
-        int w = incl - nw;
-#pragma unroll
-        for (int q = 0; q < ADJ_DEG; q++)
-            if (wins & (1u << q)) {
-                sh.winkey[w] = chi[q];
-                sh.winh[w] = hc[q];
-                w++;
-            }
-        ln_sync();
-        const bool isfree = (freemask >> lane) & 1ull;
-        const int frank = __popcll(freemask & ((1ull << lane) - 1ull));
-        if (isfree && frank < total) {
-            r.key = sh.winkey[frank];
-            sh.ent[sh.winh[frank]].y = (uint32_t)lane;
-        }
-    }
-    ln_sync();
-    return r;
-}
-
-// Children of the nodes on the lanes of `src`: lanes that hold them are returned as a mask; children
-// that are not in the frontier yet take free lanes (their records are fetched).  Returns false when
-// the free lanes do not suffice (the caller abandons the column).
-__device__ __forceinline__ bool ln_expand(const SparseModel &M, LeanShared &sh, LeanLane &L, unsigned long long src,
-                                           unsigned long long &out, int &inserted) {
-    const int lane = threadIdx.x;
-    const bool insrc = (src >> lane) & 1ull;
-    inserted = 0;
-    // the common case on a unitig: every child is in the frontier already (links resolved once per step)
-    if (__ballot(insrc && L.miss) != 0ull) {
-        const LnAdopt ad = ln_insert_children(sh, insrc, L.id != LN_EMPTY, L.r.chi[0], L.r.chi[1], L.r.chi[2], L.r.chi[3],
-                                              L.r.chi[4], (int)L.r.nchi);
-        if (ad.total < 0) return false;
-        inserted = ad.total;
-        if (ad.key != LN_EMPTY) {
-            L.id = ad.key;
-            L.r = M.fadj[ad.key];
-            L.pm = L.pi = L.pd = 0.0;
-            L.m = L.i = L.d = 0.0;
-        }
-        ln_links(sh, L);  // new nodes: their own links and everybody's links to them
-    }
-    out = ln_children_of(L, src);
+// Takes in ONE missing child: the first missing child slot of the lowest lane of `need` goes to the lowest free
+// lane (so new nodes take lanes in the order (parent lane, child slot)).  Returns false when no lane is free (the
+// caller abandons the column).  One adoption per call, and the caller loops: with the loop in here the compiler
+// keeps the lane state in scratch memory.
+__device__ __forceinline__ bool l2_take_one(const SparseModel &M, LeanFwdShared &sh, LeanLane &L, uint32_t &ahead,
+                                            unsigned long long need) {
+    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)need) - 1);
+    uint32_t mykey = L.r.chi[4];
+    if (3 < (int)L.r.nchi && l2_byte<3>(L.cl) == L2_NONE) mykey = L.r.chi[3];
+    if (2 < (int)L.r.nchi && l2_byte<2>(L.cl) == L2_NONE) mykey = L.r.chi[2];
+    if (1 < (int)L.r.nchi && l2_byte<1>(L.cl) == L2_NONE) mykey = L.r.chi[1];
+    if (0 < (int)L.r.nchi && l2_byte<0>(L.cl) == L2_NONE) mykey = L.r.chi[0];
+    const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)mykey, l);
+    const unsigned long long freem = ~__ballot(L.id != LN_EMPTY);
+    if (freem == 0ull) return false;
+    const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)freem) - 1);
+    l2_adopt(M, sh, L, ahead, key, f);
     return true;
 }
 
-__global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a) {
-    __shared__ LeanShared sh;
+// Lanes that hold a child of a node on a lane of `src` (all children are resident: l2_need(src) == 0).
+__device__ __forceinline__ unsigned long long l2_children(const LeanLane &L, unsigned long long src) {
+    return __ballot(L.id != LN_EMPTY && (L.pmask & src) != 0ull);
+}
+
+// sum over the parents of w[q] * value on the parent's lane (the value is 0 on lanes that are not a source)
+__device__ __forceinline__ double l2_parent_sum(const LeanLane &L, double v, bool on) {
+    double acc = 0.0;
+#define L2_PAR(Q)                                                \
+    {                                                            \
+        const uint32_t p = l2_byte<Q>(L.pl);                     \
+        const double u = __shfl(v, p == L2_NONE ? 0 : (int)p);   \
+        if (on && p != L2_NONE) acc += L.r.par_w[Q] * u;         \
+    }
+    L2_PAR(0) L2_PAR(1) L2_PAR(2) L2_PAR(3) L2_PAR(4)
+#undef L2_PAR
+    return acc;
+}
+
+__global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs a) {
+    __shared__ LeanFwdShared sh;
     const int lane = threadIdx.x;
     const uint32_t gi = a.lanes[blockIdx.x];
     const int g = (int)(gi / a.W), r = (int)(gi % a.W);
@@ -176,6 +212,10 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
     LeanLane L;
     L.id = LN_EMPTY;
     L.pm = L.pi = L.pd = L.m = L.i = L.d = 0.0;
+    L.pl = L.cl = L2Links{0xffffffffu, L2_NONE};
+    L.pmask = 0ull;
+    L.nres = 0;
+    uint32_t ahead = LN_EMPTY;  // node whose record was requested into sh.stage
     int E = 0;
     unsigned long long act = 0ull;  // lanes of the active list of the last finished column
     {
@@ -187,9 +227,9 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
         else {
             rec = a.pool.base + (o1 - 8);
             const int *hw = (const int *)rec;
-            n = hw[0];
-            na = hw[1];
-            E = hw[2];
+            n = __builtin_amdgcn_readfirstlane(hw[0]);
+            na = __builtin_amdgcn_readfirstlane(hw[1]);
+            E = __builtin_amdgcn_readfirstlane(hw[2]);
             if (n > 64) err |= SP_ERR_CAPACITY;  // does not fit this class
         }
         if (!err) {
@@ -204,19 +244,34 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
                 L.r = a.M.fadj[L.id];
             }
             act = na >= 64 ? ~0ull : ((1ull << na) - 1ull);
+            // links among the nodes of the column, once: every node announces itself
+            for (int j = 0; j < n; j++) {
+                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)L.id, j);
+#define L2_INIT(Q)                                                          \
+    if (lane < n && Q < (int)L.r.npar && L.r.par[Q] == key) {               \
+        l2_put<Q>(L.pl, (uint32_t)j);                                       \
+        L.pmask |= 1ull << j;                                               \
+    }                                                                       \
+    if (lane < n && Q < (int)L.r.nchi && L.r.chi[Q] == key) {               \
+        l2_put<Q>(L.cl, (uint32_t)j);                                       \
+        L.nres++;                                                           \
+    }
+                L2_INIT(0) L2_INIT(1) L2_INIT(2) L2_INIT(3) L2_INIT(4)
+#undef L2_INIT
+            }
         }
     }
     // record pool slab of this wave (wave-uniform)
     unsigned long long slab = 0ull, slab_end = 0ull;
     // InsBegin of the previous column in that column's scale (fib, forward.rs:541-545); afterwards it is
     // carried along with the exact power-of-two rescales
-    double ibs = (!err && pos < end) ? exp(a.M.logib[pos - 1] - (double)E * SP_LN2) : 0.0;
+    double ibs = l2_uniform((!err && pos < end) ? exp(a.M.logib[pos - 1] - (double)E * SP_LN2) : 0.0);
     uint8_t xn = (!err && pos < end) ? a.bases[((size_t)g * a.Lb + pos) * a.W + r] : (uint8_t)0;
 
 #ifdef PHMM_LEAN_PROF
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = 0;
-    int psteps = 0, plev = 0;
-#define PROF_T(k)                         \
+    int psteps = 0;
+#define PROF_T(k)                        \
     {                                     \
         const long long now_ = clock64(); \
         pt[k] += now_ - pc0;              \
@@ -232,46 +287,39 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
 #endif
         const uint8_t x = xn;
         if (pos + 1 < end) xn = a.bases[((size_t)g * a.Lb + pos + 1) * a.W + r];
-        // ---- node -> lane map of the resident nodes (previous column)
-        ln_rebuild(sh, L.id);
-        ln_links(sh, L);
         // ---- top = previous nodes within the ratio of the best total (table.rs:134-149)
         const double t = L.id != LN_EMPTY ? L.pm + L.pi + L.pd : 0.0;
-        const double tmax = wave_max(t);
+        const double tmax = l2_uniform(wave_max(t));
         const unsigned long long top = __ballot(t > 0.0 && t > tmax * a.ratio_lin);
         PROF_T(0)
-        // ---- one loop over the expansions of the step (a single copy of the insertion path keeps the kernel
-        // at 4 waves per SIMD): h = 0 gives active = top ++ children(top) and m, i; h = 1 .. n_max_gaps + 1 the
-        // adaptive fd levels S_0 = children(active), S_t = children(S_{t-1}) (forward.rs:423-524)
-        const double c_begin = lp.p_IM * ibs;                 // p_MM*mb' + p_IM*ib' with mb' = 0
-        const double ib_cur = lp.p_random * lp.p_II * ibs;    // fib
-        const double c_del = lp.p_ID * ib_cur;                // fd0 from_begin with mb = 0
+        // ---- the expansions of the step: h = 0 gives active = top ++ children(top) and m, i; h = 1 .. n_max_gaps + 1
+        // the adaptive fd levels S_0 = children(active), S_t = children(S_{t-1}) (forward.rs:423-524)
+        const double c_begin = l2_uniform(lp.p_IM * ibs);                 // p_MM*mb' + p_IM*ib' with mb' = 0
+        const double ib_cur = l2_uniform(lp.p_random * lp.p_II * ibs);    // fib
+        const double c_del = l2_uniform(lp.p_ID * ib_cur);                // fd0 from_begin with mb = 0
         unsigned long long members = 0ull, srcm = top;
         double lv = 0.0;  // level value handed to the next level
         bool overflow = false;
-        int ins = 0;
         L.m = L.i = L.d = 0.0;
-        for (int h = 0; h <= lp.n_max_gaps + 1; h++) {
-            unsigned long long S = 0ull;
-            if (!ln_expand(a.M, sh, L, srcm, S, ins)) {
-                overflow = true;
-                break;
+        for (int h = 0; h <= lp.n_max_gaps + 1;) {
+            // children of the source lanes that are not in the frontier come in first, one per turn of this loop
+            const unsigned long long need = l2_need(L, srcm);
+            if (need != 0ull) {
+                if (!l2_take_one(a.M, sh, L, ahead, need)) {
+                    overflow = true;
+                    break;
+                }
+                PROF_T(1)
+                continue;
             }
-#ifdef PHMM_LEAN_PROF
-            if (ins > 0) plev++;
-#endif
-            PROF_T(1)
+            const unsigned long long S = l2_children(L, srcm);
+            PROF_T(3)
             if (h == 0) {
                 act = top | S;
                 const bool is_act = (act >> lane) & 1ull;
                 // fm, fi (forward.rs:337-388)
                 const double G = lp.p_MM * L.pm + lp.p_IM * L.pi + lp.p_DM * L.pd;
-                double acc = 0.0;
-#pragma unroll
-                for (int q = 0; q < ADJ_DEG; q++) {
-                    const double v = ln_shfl(G, L.pl[q]);
-                    if (is_act && q < (int)L.r.npar && L.pl[q] >= 0) acc += L.r.par_w[q] * v;
-                }
+                const double acc = l2_parent_sum(L, G, is_act);
                 if (is_act) {
                     const double pe = L.r.emis == x ? lp.p_match : lp.p_mismatch;
                     L.m = pe * (acc + L.r.init * c_begin);
@@ -281,32 +329,23 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
                 // nodes leave now instead of at the end of the step (one that comes back as a Del-level node is
                 // fetched again), so that a wide frontier still fits the 64 lanes.
                 const unsigned long long resident = __ballot(L.id != LN_EMPTY);
-                if (64 - __popcll(resident) < 16 && (resident & ~act) != 0ull) {
-                    if (!is_act) {
-                        L.id = LN_EMPTY;
-                        L.pm = L.pi = L.pd = 0.0;
-                    }
-                    ln_rebuild(sh, L.id);
-                    ln_links(sh, L);
-                }
+                if (64 - __popcll(resident) < 16 && (resident & ~act) != 0ull) l2_evict(L, resident & ~act);
                 members = act;
                 srcm = act;
                 lv = lp.p_MD * L.m + lp.p_ID * L.i;
+                h++;
                 PROF_T(2)
                 continue;
             }
             const bool inS = (S >> lane) & 1ull;
-            double s = 0.0;
-#pragma unroll
-            for (int q = 0; q < ADJ_DEG; q++) {
-                const double v = ln_shfl(lv, L.pl[q]);
-                if (inS && q < (int)L.r.npar && L.pl[q] >= 0 && ((srcm >> L.pl[q]) & 1ull)) s += L.r.par_w[q] * v;
-            }
+            // (the level value is 0 on every lane outside the previous level's set)
+            const double s = l2_parent_sum(L, lv, inS);
             const double val = h == 1 ? s + L.r.init * c_del : lp.p_DD * s;
             if (inS) L.d += val;
             lv = inS ? val : 0.0;
             srcm = S;
             members |= S;
+            h++;
             PROF_T(4)
             if (S == 0ull) break;
         }
@@ -319,12 +358,12 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
         double mx = member ? fmax(fmax(L.m, L.i), L.d) : 0.0;
         mx = wave_max(fmax(mx, ib_cur));
         const int e = sp_exp_of(mx);
-        const double sc = sp_pow2(-e);
+        const double sc = l2_uniform(sp_pow2(-e));
         L.m *= sc;
         L.i *= sc;
         L.d *= sc;
         E += e;
-        ibs = ib_cur * sc;
+        ibs = l2_uniform(ib_cur * sc);
         PROF_T(5)
         // ---- store the column: active entries first, then the Del-only ones
         {
@@ -366,23 +405,24 @@ __global__ void __launch_bounds__(64) lean_forward_kernel(const SparseFwdArgs a)
             }
         }
         // ---- the column becomes the previous one; nodes that left the frontier free their lanes
+        {
+            const unsigned long long gone = __ballot(L.id != LN_EMPTY) & ~members;
+            if (gone != 0ull) l2_evict(L, gone);
+        }
         if (member) {
             L.pm = L.m;
             L.pi = L.i;
             L.pd = L.d;
-        } else {
-            L.id = LN_EMPTY;
-            L.pm = L.pi = L.pd = 0.0;
         }
         done_to = pos + 1;
         PROF_T(6)
     }
 #ifdef PHMM_LEAN_PROF
     if (blockIdx.x == 0 && lane == 0 && psteps > 0)
-        printf("lean_fwd prof: steps %d insertions %d | rebuild+top %lld expand %lld links+fm %lld compact %lld del %lld rescale %lld store %lld (cycles/step)\n",
-               psteps, plev, pt[0] / psteps, pt[1] / psteps, pt[2] / psteps, pt[3] / psteps, pt[4] / psteps, pt[5] / psteps,
-               pt[6] / psteps);
+        printf("lean_fwd prof: steps %d | top %lld take-in %lld children %lld fm %lld del %lld rescale %lld store %lld (cycles/step)\n", psteps,
+               pt[0] / psteps, pt[1] / psteps, pt[3] / psteps, pt[2] / psteps, pt[4] / psteps, pt[5] / psteps, pt[6] / psteps);
 #endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no fetch-ahead may outlive the wave's use of LDS
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
     const bool finished = !err && done_to >= len;
     double lpv = NAN;
