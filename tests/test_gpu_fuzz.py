@@ -4,7 +4,7 @@ Del-chain length).  tools/fuzz_parity.py runs the same cases in bulk (round 2: 1
 import numpy as np
 import pytest
 
-from fuzz_cases import check_case, make_case
+from fuzz_cases import check_case, check_case_medium, make_case, make_case_medium
 
 pytestmark = pytest.mark.gpu
 
@@ -17,3 +17,11 @@ def test_random_cases_match_oracle(gpu_lib, oracle):
         seen["forced" if "forced=" in tag else "plain"] += 1
         seen["tie"] += "tie-order" in tag
     assert seen["plain"] >= 10, seen  # (most cases run the whole comparison)
+
+
+def test_random_medium_cases_match_oracle(gpu_lib, oracle):
+    """15-60 kb genomes at k = 24..40, 70-260 reads of 300-1500 bases (several read groups; the oracle runs on a
+    sample of each set that always holds the reads that took the rarer routes)."""
+    rng = np.random.default_rng(20261006)
+    for case in range(5):
+        check_case_medium(make_case_medium(rng, case))
