@@ -15,6 +15,9 @@
 
 namespace phmm {
 
+// a rescale exponent below this in ONE position: see hinted_exact_kernel
+static constexpr int HINT_COLLAPSE_EXP = -512;
+
 struct HintedArgs {
     SparseModel M;
     const double *init_c;   // [C][N] linear
@@ -53,6 +56,7 @@ __global__ void __launch_bounds__(64) hinted_score_kernel(const HintedArgs a) {
     }
     wave_sync();
     int pos = 0;
+    bool collapse = false;
     for (; pos < len; pos++) {
         const uint64_t o0 = a.map_pos_off[b0 + pos], o1 = a.map_pos_off[b0 + pos + 1];
         const int n = (int)(o1 - o0);
@@ -62,10 +66,13 @@ __global__ void __launch_bounds__(64) hinted_score_kernel(const HintedArgs a) {
         }
         err |= fwd_list_step<CAP, LPN>(M, cols[(pos + 1) & 1], cols[pos & 1], a.map_nodes + o0, n, a.bases[b0 + pos],
                                        pos == 0, pos, lnk_slot, lnk_w, dA, dB);
+        // a column 2^-512 below the one before it: every listed node died and what is left restarts from an InsBegin
+        // chain that is down among the denormals (or below) -- not trusted, see hinted_exact_kernel
+        if (pos > 0 && cols[pos & 1].E - cols[(pos + 1) & 1].E < HINT_COLLAPSE_EXP) collapse = true;
         if (a.pool.base && cand == 0 && !store_record_col<CAP>(a.pool, b0 + pos, cols[pos & 1])) err |= SP_ERR_POOL;
     }
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
-    const double lp = err ? NAN : col_log_end(M, cols[(len - 1) & 1]);
+    const double lp = err ? NAN : (collapse ? -INFINITY : col_log_end(M, cols[(len - 1) & 1]));
     if (threadIdx.x == 0) {
         a.out_logp[(size_t)cand * a.R + rd] = lp;
         a.err[(size_t)cand * a.R + rd] = err;
@@ -153,6 +160,7 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
     // previous column on the lanes of ITS list order
     double pm = 0.0, pi = 0.0, pd = 0.0, m = 0.0, ii = 0.0, d = 0.0, ibs = 0.0;
     int Eprev = 0, n_prev = 0;
+    bool collapse = false;
 #ifdef PHMM_LEAN_PROF
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = 0;
 #define HPROF(k)                          \
@@ -261,6 +269,7 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
         // ---- rescale so that the column maximum is in [0.5, 1)
         const double mx = wave_max(fmax(has ? fmax(fmax(m, ii), d) : 0.0, ib_cur));
         const int e = sp_exp_of(mx);
+        collapse |= !first && e < HINT_COLLAPSE_EXP;
         const double sc = sp_pow2(-e);
         m = __dmul_rn(m, sc);
         ii = __dmul_rn(ii, sc);
@@ -321,7 +330,7 @@ __global__ void __launch_bounds__(64) hinted_lean_kernel(const HintedArgs a) {
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
     // fe (forward.rs:554-558) of the last column
     const double stot = wave_sum(lane < n_prev ? __dadd_rn(__dadd_rn(pm, pi), pd) : 0.0);
-    const double lpv = err ? NAN : HStep::log_end(lp, stot, Eprev);
+    const double lpv = err ? NAN : (collapse ? -INFINITY : HStep::log_end(lp, stot, Eprev));
     if (lane == 0) {
         a.out_logp[(size_t)cand * a.R + rd] = lpv;
         a.err[(size_t)cand * a.R + rd] = err;
@@ -411,10 +420,12 @@ __global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, c
     uint8_t x_cur = a.bases[b0], x_nx = len >= 2 ? a.bases[b0 + 1] : (uint8_t)0;
     double pm[CPL], pi[CPL], pd[CPL], ibs[CPL];
     int Eprev[CPL];
+    bool collapse[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         pm[c] = pi[c] = pd[c] = ibs[c] = 0.0;
         Eprev[c] = 0;
+        collapse[c] = false;
     }
     int n_prev = 0;
     for (int pos = 0; pos < len; pos++) {
@@ -540,6 +551,7 @@ __global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, c
             // rescale so that the column maximum of THIS candidate is in [0.5, 1)
             const double mx = group_max<WG>(fmax(fmax(fmax(m, ii), d), ib_cur));
             const int e = sp_exp_of(mx);
+            collapse[c] |= !first && e < HINT_COLLAPSE_EXP;
             const double sc = sp_pow2(-e);
             pm[c] = __dmul_rn(m, sc);
             pi[c] = __dmul_rn(ii, sc);
@@ -581,12 +593,200 @@ __global__ void __launch_bounds__(64) hinted_packed_kernel(const HintedArgs a, c
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const double stot = group_sum<WG>(slot < n_prev ? __dadd_rn(__dadd_rn(pm[c], pi[c]), pd[c]) : 0.0, slot);
-        const double lpv = err ? NAN : HStep::log_end(lp, stot, Eprev[c]);
+        const double lpv = err ? NAN : (collapse[c] ? -INFINITY : HStep::log_end(lp, stot, Eprev[c]));
         if (slot == 0 && cand_ok[c]) {
             a.out_logp[(size_t)cand[c] * a.R + rd] = lpv;
             a.err[(size_t)cand[c] * a.R + rd] = err;
         }
     }
+}
+
+// ---- wide-range fallback of the hinted forward -----------------------------------------------------------
+// forward_with_mappings (forward.rs:79-89, 276-306, 337-388, 423-524, 541-558: fm, fi, fib, fd0 + n_max_gaps x fdt
+// over the position's list, fe at the end) with EVERY value carrying its own binary exponent -- a double mantissa
+// in [0.5, 1) and an int exponent -- so that nothing underflows whatever its distance from the column's best value:
+// the range of the reference's natural-log f64 with plain multiply-adds instead of a log-sum-exp per term.  One
+// wave per (candidate, read).  It runs for the pairs the scaled kernels returned -inf for.  That happens when every
+// node of a read's lists dies -- a candidate that sets a k-mer on the read's path to copy number 0 -- hundreds of
+// positions into the read: the reference then still holds the InsBegin chain (p_random * p_II per base, never
+// zero), which re-enters the graph behind the cut, and returns a finite ln P of about -7 per base of the cut-off
+// prefix.  In the scaled linear domain (ONE exponent per column) that chain is 2^-1075 below the read's own path
+// after ~105 bases and is gone, so the restart is lost; here it is not.
+struct XF {
+    double m;  // 0, or in [0.5, 1)
+    int e;
+};
+__device__ __forceinline__ XF xf_norm(double v, int e) {
+    if (v == 0.0) return XF{0.0, 0};
+    int k;
+    const double m = frexp(v, &k);
+    return XF{m, e + k};
+}
+__device__ __forceinline__ XF xf_from(double p) { return xf_norm(p, 0); }
+__device__ __forceinline__ XF xf_mul(XF a, double p) { return xf_norm(a.m * p, a.e); }
+__device__ __forceinline__ XF xf_mulx(XF a, XF b) { return xf_norm(a.m * b.m, a.e + b.e); }
+__device__ __forceinline__ XF xf_add(XF a, XF b) {
+    if (a.m == 0.0) return b;
+    if (b.m == 0.0) return a;
+    if (a.e < b.e) {
+        const XF t = a;
+        a = b;
+        b = t;
+    }
+    const int d = b.e - a.e;
+    if (d < -1000) return a;
+    return xf_norm(a.m + ldexp(b.m, d), a.e);
+}
+__device__ __forceinline__ double xf_log(XF a) { return a.m == 0.0 ? -INFINITY : log(a.m) + (double)a.e * SP_LN2; }
+
+// (two sizes: lists of up to 64 nodes -- nearly every read -- keep 9 KB of LDS per wave, so that thousands of pairs
+// run at once; the full 400-slot version holds 46 KB)
+template <int XCAP, int XHASH> struct ExactCol {
+    uint32_t id[XCAP];
+    double m[XCAP], i[XCAP], d[XCAP];
+    int me[XCAP], ie[XCAP], de[XCAP];
+    uint32_t hkey[XHASH];
+    uint16_t hval[XHASH];
+};
+template <int XCAP, int XHASH> __device__ __forceinline__ int xl_find(const ExactCol<XCAP, XHASH> &c, uint32_t key) {
+    uint32_t h = ((key * 2654435761u) >> 16) & (XHASH - 1);
+    for (;;) {
+        const uint32_t k = c.hkey[h];
+        if (k == key) return (int)c.hval[h];
+        if (k == 0xffffffffu) return -1;
+        h = (h + 1) & (XHASH - 1);
+    }
+}
+template <int XCAP, int XHASH>
+__global__ void __launch_bounds__(64) hinted_exact_kernel(const HintedArgs a, const uint2 *pairs, double *res) {
+    typedef ExactCol<XCAP, XHASH> XCol;
+    __shared__ XCol cols[2];
+    __shared__ double ta[XCAP], tb[XCAP];
+    __shared__ int tae[XCAP], tbe[XCAP];
+    const int lane = threadIdx.x;
+    const uint32_t cand = pairs[blockIdx.x].x, rd = pairs[blockIdx.x].y;
+    const double *init = a.init_c + (size_t)cand * a.M.N;
+    const double *trans = a.trans_c + (size_t)cand * a.E;
+    const LinParams &lp = a.M.lp;
+    const uint64_t b0 = a.read_off[rd], len = a.read_off[rd + 1] - b0;
+    XF mb = xf_from(1.0), ib = XF{0.0, 0};  // f_init (forward.rs:255-266)
+    int np = 0, cur = 0;
+    bool bad = false;
+    for (uint64_t pos = 0; pos < len; pos++, cur ^= 1) {
+        XCol &C = cols[cur];
+        const XCol &P = cols[cur ^ 1];
+        const uint64_t e0 = a.map_pos_off[b0 + pos];
+        const int n = (int)(a.map_pos_off[b0 + pos + 1] - e0);
+        if (n > XCAP) {
+            bad = true;
+            break;
+        }
+        const uint8_t x = a.bases[b0 + pos];
+        for (int h = lane; h < XHASH; h += 64) C.hkey[h] = 0xffffffffu;
+        wave_sync();
+        for (int j = lane; j < n; j += 64) {
+            const uint32_t k = a.map_nodes[e0 + j];
+            C.id[j] = k;
+            uint32_t h = ((k * 2654435761u) >> 16) & (XHASH - 1);
+            for (;;) {
+                const uint32_t old = atomicCAS(&C.hkey[h], 0xffffffffu, k);
+                if (old == 0xffffffffu) {
+                    C.hval[h] = (uint16_t)j;
+                    break;
+                }
+                if (old == k) break;  // (a node listed twice: the first entry stands)
+                h = (h + 1) & (XHASH - 1);
+            }
+        }
+        wave_sync();
+        // fm, fi from the previous column (empty at pos 0)
+        const XF beg_m = xf_add(xf_mul(mb, lp.p_MM), xf_mul(ib, lp.p_IM));
+        for (int j = lane; j < n; j += 64) {
+            const uint32_t k = C.id[j];
+            XF from_normal{0.0, 0};
+            for (uint32_t e = a.M.par_off[k]; e < a.M.par_off[k + 1]; e++) {
+                const int q = np > 0 ? xl_find(P, a.M.par_node[e]) : -1;
+                if (q < 0) continue;
+                const XF inner = xf_add(xf_add(xf_mul(XF{P.m[q], P.me[q]}, lp.p_MM), xf_mul(XF{P.i[q], P.ie[q]}, lp.p_IM)),
+                                        xf_mul(XF{P.d[q], P.de[q]}, lp.p_DM));
+                from_normal = xf_add(from_normal, xf_mul(inner, trans[a.M.par_edge[e]]));
+            }
+            const XF mv = xf_mul(xf_add(from_normal, xf_mul(beg_m, init[k])), a.M.emis[k] == x ? lp.p_match : lp.p_mismatch);
+            C.m[j] = mv.m;
+            C.me[j] = mv.e;
+            const int me = np > 0 ? xl_find(P, k) : -1;
+            XF iv{0.0, 0};
+            if (me >= 0)
+                iv = xf_mul(xf_add(xf_add(xf_mul(XF{P.m[me], P.me[me]}, lp.p_MI), xf_mul(XF{P.i[me], P.ie[me]}, lp.p_II)),
+                                   xf_mul(XF{P.d[me], P.de[me]}, lp.p_DI)),
+                            lp.p_random);
+            C.i[j] = iv.m;
+            C.ie[j] = iv.e;
+        }
+        ib = xf_mul(xf_add(xf_mul(mb, lp.p_MI), xf_mul(ib, lp.p_II)), lp.p_random);  // fib; fmb = 0
+        mb = XF{0.0, 0};
+        wave_sync();
+        // fd0 from this column's m, i; then the Del levels over the same list
+        const XF beg_d = xf_mul(ib, lp.p_ID);  // (mb = 0)
+        for (int j = lane; j < n; j += 64) {
+            const uint32_t k = C.id[j];
+            XF from_normal{0.0, 0};
+            for (uint32_t e = a.M.par_off[k]; e < a.M.par_off[k + 1]; e++) {
+                const int q = xl_find(C, a.M.par_node[e]);
+                if (q < 0) continue;
+                const XF g = xf_add(xf_mul(XF{C.m[q], C.me[q]}, lp.p_MD), xf_mul(XF{C.i[q], C.ie[q]}, lp.p_ID));
+                from_normal = xf_add(from_normal, xf_mul(g, trans[a.M.par_edge[e]]));
+            }
+            const XF v = xf_add(from_normal, xf_mul(beg_d, init[k]));
+            ta[j] = v.m;
+            tae[j] = v.e;
+            C.d[j] = v.m;
+            C.de[j] = v.e;
+        }
+        double *src = ta, *dst = tb;
+        int *srce = tae, *dste = tbe;
+        for (int t = 0; t < lp.n_max_gaps; t++) {
+            wave_sync();
+            for (int j = lane; j < n; j += 64) {
+                const uint32_t k = C.id[j];
+                XF sacc{0.0, 0};
+                for (uint32_t e = a.M.par_off[k]; e < a.M.par_off[k + 1]; e++) {
+                    const int q = xl_find(C, a.M.par_node[e]);
+                    if (q < 0) continue;
+                    sacc = xf_add(sacc, xf_mul(XF{src[q], srce[q]}, trans[a.M.par_edge[e]] * lp.p_DD));
+                }
+                dst[j] = sacc.m;
+                dste[j] = sacc.e;
+                const XF dv = xf_add(XF{C.d[j], C.de[j]}, sacc);
+                C.d[j] = dv.m;
+                C.de[j] = dv.e;
+            }
+            double *tmp = src;
+            src = dst;
+            dst = tmp;
+            int *tmpe = srce;
+            srce = dste;
+            dste = tmpe;
+        }
+        wave_sync();
+        np = n;
+    }
+    // fe over the last column's list
+    double lpv = -INFINITY;
+    if (!bad && len > 0) {
+        const XCol &L = cols[cur ^ 1];
+        XF e{0.0, 0};
+        for (int j = lane; j < np; j += 64)
+            e = xf_add(e, xf_add(xf_add(XF{L.m[j], L.me[j]}, XF{L.i[j], L.ie[j]}), XF{L.d[j], L.de[j]}));
+        for (int off = 32; off >= 1; off >>= 1) {
+            XF o;
+            o.m = __shfl_xor(e.m, off);
+            o.e = __shfl_xor(e.e, off);
+            e = xf_add(e, o);
+        }
+        lpv = xf_log(xf_mul(e, lp.p_end));
+    }
+    if (lane == 0) res[blockIdx.x] = bad ? NAN : lpv;
 }
 
 __global__ void __launch_bounds__(256) exp_kernel(const double *in, double *out, size_t n) {
@@ -848,6 +1048,37 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
     }
     HIP_CHECK(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    // (candidate, read) pairs that came back -inf: the reference's InsBegin chain may still carry them (see
+    // hinted_exact_kernel) -- recomputed in its own arithmetic
+    if (!pool && std::getenv("PHMM_NO_EXACT_HINTED") == nullptr) {
+        std::vector<uint2> pairs;
+        for (uint32_t k = 0; k < n_cand; k++)
+            for (uint64_t r = 0; r < R; r++)
+                if (h_out[(size_t)k * R + r] == -INFINITY && reads->off[r + 1] > reads->off[r]) pairs.push_back(make_uint2(k, (uint32_t)r));
+        if (!pairs.empty()) {
+            // short lists first (the small kernel), the rest behind them
+            const size_t n_small = (size_t)(std::stable_partition(pairs.begin(), pairs.end(),
+                                                                  [&](const uint2 &q) { return mp->read_max_list[q.y] <= 64; }) -
+                                            pairs.begin());
+            DevBuf &d_pairs = m->wset().aux[10];  // (the read ids of the classes are spent)
+            d_pairs.reserve(pairs.size() * (sizeof(uint2) + sizeof(double)) + 256);
+            uint2 *dp = d_pairs.as<uint2>();
+            double *dres = (double *)(d_pairs.as<char>() + (pairs.size() * sizeof(uint2) + 255) / 256 * 256);
+            HIP_CHECK(hipMemcpyAsync(dp, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+            if (n_small)
+                hipLaunchKernelGGL((hinted_exact_kernel<64, 256>), dim3((unsigned)n_small), dim3(64), 0, s, a, (const uint2 *)dp, dres);
+            if (n_small < pairs.size())
+                hipLaunchKernelGGL((hinted_exact_kernel<PHMM_MAX_ACTIVE_NODES, 1024>), dim3((unsigned)(pairs.size() - n_small)),
+                                   dim3(64), 0, s, a, (const uint2 *)(dp + n_small), dres + n_small);
+            HIP_CHECK(hipGetLastError());
+            std::vector<double> hres(pairs.size());
+            HIP_CHECK(hipMemcpyAsync(hres.data(), dres, hres.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            for (size_t q = 0; q < pairs.size(); q++)
+                if (hres[q] == hres[q]) h_out[(size_t)pairs[q].x * R + pairs[q].y] = hres[q];
+            st.launches[2]++;
+        }
+    }
     st.ms[2] += tm.stop();
     cells = mp->total_entries;
     st.cells[2] = cells * n_cand;

@@ -111,10 +111,23 @@ def test_cfg3_candidate_batch_packs_candidates(cfg3, monkeypatch):
         ix = rng.integers(0, cn.shape[1], size=40)
         cn[c, ix] = np.maximum(cn[c, ix].astype(np.int64) + rng.choice([-1, 1], size=40), 0).astype(np.uint32)
     tot, lp = gm.to_full_prob_reads_copy_nums(rc, mp, cn, 0)
-    assert np.isneginf(lp[1:]).any() and np.all(np.isfinite(lp[0]))  # a k-mer set to 0 kills the reads through it
+    # A k-mer set to 0 cuts the reads through it: every node of their lists dies there.  The reference still carries
+    # the InsBegin chain (p_random p_II per base), which re-enters the graph behind the cut: a finite ln P of about -7
+    # per base of the cut-off prefix.  The scaled kernels lose that chain (it underflows after ~105 bases); such
+    # pairs are recomputed in the reference's log-space arithmetic (sparse.hip: hinted_exact_kernel).
+    assert np.all(np.isfinite(lp)) and (lp[1:] < -500.0).any()
+    dead = np.argwhere(lp < -500.0)
+    for c, r in dead[:: max(1, len(dead) // 4)][:4]:
+        with np.errstate(divide="ignore"):
+            a2 = D.vectorised_to_phmm(D.SeqGraph(cn[c], sg.base, sg.edge_src, sg.edge_dst, None), arrays.param, 0)
+        from oracle import oracle as O
+        O.build()
+        sub = subset_csr(rc.offsets.astype(np.int64), mp.arrays(), [int(r)])
+        ol = O.Model(a2).full_prob_reads([cfg3["reads"][int(r)]], sub, True, n_threads=1)[0]
+        assert abs(ol - lp[c, r]) < 1e-6, (int(c), int(r), ol, lp[c, r])
     for c in (0, 4, 10):
         t1, lp1 = gm.to_full_prob_reads_copy_nums(rc, mp, cn[c:c + 1], 0)  # one candidate: the one-candidate kernels
-        assert np.array_equal(lp1[0], lp[c]) and (t1[0] == tot[c] or (np.isneginf(t1[0]) and np.isneginf(tot[c])))
+        assert np.array_equal(lp1[0], lp[c]) and t1[0] == tot[c]
     monkeypatch.setenv("PHMM_NO_PACKED", "1")
     tot2, lp2 = gm.to_full_prob_reads_copy_nums(rc, mp, cn, 0)
     assert np.array_equal(lp2, lp)

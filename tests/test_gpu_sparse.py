@@ -116,6 +116,51 @@ def test_candidate_batch_packed_kernels_all_widths(gpu_lib, oracle, cpl, monkeyp
             assert np.all((np.isneginf(ol) & np.isneginf(lp[c])) | (np.abs(ol - lp[c]) < TOL_LOGP))
 
 
+def test_reads_cut_by_a_zero_copy_kmer_keep_the_begin_chain(gpu_lib, oracle, monkeypatch):
+    """A candidate that sets a k-mer on a read's path to copy number 0 kills every node of the read's lists at that
+    position.  The reference's ln P stays finite: the InsBegin chain (p_random p_II per base) re-enters the graph
+    behind the cut (forward.rs:337-359 from_begin, 541-545).  In the scaled linear domain that chain underflows
+    ~105 bases into the read; such pairs are recomputed in log space (sparse.hip: hinted_exact_kernel) -- for all
+    three kernel classes, for candidates given as copy numbers, as probability vectors, and for a model built with
+    the zero already in it."""
+    arrays, sg, reads, om, mp = _setup(oracle, genome_len=900, k=12, p=0.003, n_reads=40, seed=21, read_len=420)
+    reads = [r for r in reads if len(r) > 380][:24]
+    (po, nd, lpm), _ = om.generate_mappings(reads, None, True, n_threads=8)
+    mp = (po, nd, lpm)
+    rc = D.ReadCollection(reads)
+    gm = D.PHMMModel(arrays)
+    gmp = D.Mappings.from_arrays(rc, *mp)
+    # the best node of base 300 of read 0 goes to zero: reads through it are cut ~300 bases in (past the underflow)
+    off = rc.offsets.astype(np.int64)
+    victim = int(nd[int(po[off[0] + 300])])
+    cn0 = sg.copy_num.copy()
+    cn1 = cn0.copy()
+    cn1[victim] = 0
+    with np.errstate(divide="ignore"):
+        a1 = D.vectorised_to_phmm(D.SeqGraph(cn1, sg.base, sg.edge_src, sg.edge_dst, None), arrays.param, 0)
+    ol = oracle.Model(a1).full_prob_reads(reads, mp, True, n_threads=8)
+    healthy = om.full_prob_reads(reads, mp, True, n_threads=8)
+    cut = np.flatnonzero(ol < healthy - 200.0)
+    assert cut.size >= 2 and np.all(np.isfinite(ol))
+    for env in ({}, {"PHMM_NO_PACKED": "1"}, {"PHMM_NO_PACKED": "1", "PHMM_NO_LEAN": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        tot, lp = gm.to_full_prob_reads_copy_nums(rc, gmp, np.stack([cn0, cn1, cn1]), 0)
+        assert np.max(np.abs(lp[1] - ol)) < 1e-9 and np.array_equal(lp[1], lp[2]), env
+        assert np.max(np.abs(lp[0] - healthy)) < 1e-9
+        assert abs(tot[1] - ol.sum()) < 1e-6
+        t2, lp2 = gm.to_full_prob_reads_candidates(rc, gmp, a1.init_logp[None, :], a1.trans_logp[None, :])
+        assert np.max(np.abs(lp2[0] - ol)) < 1e-9
+        _, lp3 = D.PHMMModel(a1).to_full_prob_reads(rc, gmp)
+        assert np.max(np.abs(lp3 - ol)) < 1e-9
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    # without the fallback the cut reads come back -inf
+    monkeypatch.setenv("PHMM_NO_EXACT_HINTED", "1")
+    _, lp4 = gm.to_full_prob_reads_copy_nums(rc, gmp, np.stack([cn1]), 0)
+    assert np.all(np.isneginf(lp4[0][cut]))
+
+
 def test_candidate_copy_numbers_on_device(gpu_lib, oracle):
     """candidates as copy-number vectors: init / trans built on the device (seq_graph.rs:160-209) give the
     same likelihoods as the host-built probability vectors, for to_phmm (min 0) and to_non_zero_phmm (min 1)."""
