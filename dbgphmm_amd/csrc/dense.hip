@@ -935,8 +935,9 @@ __global__ void __launch_bounds__(BLOCK) edge_freq_kernel(const DenseArgs a, con
         const int *BE = a.BE + (size_t)g * (a.Lc + 1) * W + r;
         for (int i = is_edge ? 1 : 0; i <= len; i++) {
             // source side: F.table_merged(i)
-            double sm, sd;  // coefficients of the "to Match" and "to Del" terms, in units of 2^fe
+            double sm, sd;  // coefficients of the "to Match" and "to Del" terms, in units of 2^fe * exp(lib)
             int fe = 0;
+            double lib = 0.0;
             if (is_edge) {
                 const size_t ix = ((size_t)g * a.Lc + (i - 1)) * NW + (size_t)k * W + r;
                 const double fm = a.Fm[ix], fi = a.Fi[ix], fd = a.Fd[ix];
@@ -947,9 +948,11 @@ __global__ void __launch_bounds__(BLOCK) edge_freq_kernel(const DenseArgs a, con
                 sm = lp.p_MM;
                 sd = lp.p_MD;
             } else {
-                const double ib = exp(a.logib[i - 1]);
-                sm = lp.p_IM * ib;
-                sd = lp.p_ID * ib;
+                // (the InsBegin chain stays in the exponent: exp(logib) alone is 0 from base ~105 on, and 0 times the
+                // exp(-ln P) = inf of a read with ln P < -709 would be NaN)
+                sm = lp.p_IM;
+                sd = lp.p_ID;
+                lib = a.logib[i - 1];
             }
             // target side
             double term = 0.0;
@@ -965,11 +968,15 @@ __global__ void __launch_bounds__(BLOCK) edge_freq_kernel(const DenseArgs a, con
                     bm = lp.p_end;
                     be = 0;
                 }
-                term += sm * pe * bm * exp((double)(fe + be) * LN2 - lpf);
+                // (a zero factor stays zero whatever the weight: no 0 * inf)
+                const double v1 = sm * pe * bm;
+                if (v1 != 0.0) term += v1 * exp(lib + (double)(fe + be) * LN2 - lpf);
                 const double bd = a.Bd[((size_t)g * a.bcols + i) * NW + (size_t)l * W + r];
-                term += sd * bd * exp((double)(fe + BE[(size_t)i * W]) * LN2 - lpf);
+                const double v2 = sd * bd;
+                if (v2 != 0.0) term += v2 * exp(lib + (double)(fe + BE[(size_t)i * W]) * LN2 - lpf);
             } else {
-                term += sd * lp.p_end * exp((double)fe * LN2 - lpf);
+                const double v3 = sd * lp.p_end;
+                if (v3 != 0.0) term += v3 * exp(lib + (double)fe * LN2 - lpf);
             }
             acc += t * term;
         }

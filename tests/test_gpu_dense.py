@@ -178,6 +178,21 @@ def test_edge_and_init_freqs_match_oracle(gpu_lib, oracle, n_reads):
     assert abs(nf.sum() - len(reads)) < 0.01 * len(reads)
 
 
+def test_edge_and_init_freqs_of_a_read_below_exp_range(gpu_lib, oracle):
+    """A long noisy read whose ln P is below -709 (exp(-ln P) overflows a double): the Begin-state posteriors multiply
+    the InsBegin chain -- itself below the double range from base ~105 on -- with that weight; the product is formed
+    in the exponent (0 * inf was NaN; found by the randomised cases)."""
+    arrays, _ = small_dbg_model(2600, 12, 0.05, seed=31)
+    read = D.sample_reads(arrays, 10 ** 9, 2400, seed=4, max_reads=1)[0]
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    lf, ef, nf = gm.run_dense_edge_freqs(D.ReadCollection([read]))
+    o = om.run(read)
+    assert o.to_full_prob_forward() < -720.0 and abs(lf[0] - o.to_full_prob_forward()) < 1e-6
+    oe, on = o.to_edge_and_init_freqs()
+    assert np.all(np.isfinite(ef)) and np.all(np.isfinite(nf))
+    assert np.max(np.abs(ef - oe)) < 1e-6 and np.max(np.abs(nf - on)) < 1e-6
+
+
 def test_chimeric_read_takes_the_exact_path(gpu_lib, oracle):
     """A read whose halves come from different places: cells thousands of nats below the column maximum grow back
     after the junction.  The scaled linear kernels flush them; the driver's certificate (exact_dense.hip:
