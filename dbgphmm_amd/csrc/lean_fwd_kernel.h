@@ -59,7 +59,7 @@ static_assert(sizeof(FwdAdj) == 96, "six 16-byte pieces are fetched ahead");
 // LDS (no register, no wait until it is read).  On a unitig the node that enters is the first child of the one
 // that entered before it.
 struct LeanFwdShared {
-    uint32_t stage[32];  // 96 bytes used
+    alignas(16) uint32_t stage[32];  // 96 bytes used (read back as one FwdAdj: 16-byte LDS reads)
 };
 
 // a wave-uniform double, told to the compiler (kept in scalar registers)
