@@ -178,7 +178,10 @@ void phmm_mappings_destroy(phmm_mappings *mp);
  * forward_with_mapping_score_only (forward.rs:79-89) when mappings != NULL, else
  * forward_sparse_score_only(use_max_ratio) (forward.rs:158-206).
  *   out_logp[R] per-read ln P; out_total = their sum (rayon `.product()`).
- * Either may be NULL / a device pointer. */
+ * Either may be NULL / a device pointer.
+ * With mappings, a read whose listed nodes all die under the model (a k-mer on its path at copy
+ * number 0) still gets the reference's finite ln P: the InsBegin chain re-enters the graph behind the
+ * cut (forward.rs:337-359, 541-545); -inf only where the reference's own value is -inf. */
 int phmm_full_prob_reads(phmm_model *m, const phmm_reads *reads,
                          const phmm_mappings *mappings, int use_max_ratio,
                          double *out_logp, double *out_total);
