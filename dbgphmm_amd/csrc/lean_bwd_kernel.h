@@ -316,9 +316,24 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         }
         ln_sync();
         PROFB_T(2)
-        // ---- child links
-        int cl[ADJ_DEG];
+        // ---- child links.  cmax: a wave-uniform bound on the child counts of the nodes on the lanes (2 on most of a
+        // diploid DBG) -- the slot loops below skip the slots nobody uses
+        int cmax = 1;
         {
+            const int nch = id != LN_EMPTY ? (int)R.nchi : 0;
+            for (int q = 1; q < ADJ_DEG; q++)
+                if (__ballot(nch > q) != 0ull) cmax = q + 1;
+        }
+        int cl[ADJ_DEG];
+        if (cmax <= 2) {
+            const uint32_t ck[2] = {R.chi[0], R.chi[1]};
+            const bool cv[2] = {sel && 0 < (int)R.nchi, sel && 1 < (int)R.nchi};
+            int c2[2];
+            ln_find_many<2>(sh.h, ck, cv, c2);
+            cl[0] = c2[0];
+            cl[1] = c2[1];
+            cl[2] = cl[3] = cl[4] = -1;
+        } else {
             uint32_t ck[ADJ_DEG];
             bool cv[ADJ_DEG];
 #pragma unroll
@@ -336,6 +351,7 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         double a1 = 0.0;
 #pragma unroll
         for (int q = 0; q < ADJ_DEG; q++) {
+            if (q >= cmax) continue;
             const double v = ln_shfl(pm, cl[q]);
             if (sel && q < (int)R.nchi && R.chi_w[q] != 0.0) {
                 double mu = 0.0;
@@ -353,6 +369,7 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
             double s = 0.0;
 #pragma unroll
             for (int q = 0; q < ADJ_DEG; q++) {
+                if (q >= cmax) continue;
                 const double v = ln_shfl(lv, cl[q]);
                 if (sel && q < (int)R.nchi && cl[q] >= 0 && ((selm >> cl[q]) & 1ull)) s += R.chi_w[q] * v;
             }
@@ -364,6 +381,7 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         double td = 0.0;
 #pragma unroll
         for (int q = 0; q < ADJ_DEG; q++) {
+            if (q >= cmax) continue;
             const double v = ln_shfl(dsum, cl[q]);
             if (sel && q < (int)R.nchi && cl[q] >= 0 && ((selm >> cl[q]) & 1ull)) td += R.chi_w[q] * v;
         }

@@ -68,7 +68,9 @@ __device__ __forceinline__ double l2_uniform(double v) {
 }
 
 // The lanes in `gone` leave the frontier: cut them out of everybody's links.
-__device__ __forceinline__ void l2_evict(LeanLane &L, unsigned long long gone) {
+// (`dmax`, here and below: a wave-uniform bound on the parent and child counts of every node that has been on a lane --
+// 2 on most of a diploid DBG -- so that the slot loops skip the slots nobody uses)
+__device__ __forceinline__ void l2_evict(LeanLane &L, unsigned long long gone, int dmax) {
     if ((gone >> threadIdx.x) & 1ull) {
         L.id = LN_EMPTY;
         L.pm = L.pi = L.pd = 0.0;
@@ -76,11 +78,13 @@ __device__ __forceinline__ void l2_evict(LeanLane &L, unsigned long long gone) {
     L.pmask &= ~gone;
     for (unsigned long long gm = gone; gm != 0ull; gm &= gm - 1ull) {
         const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane(__ffsll((long long)gm) - 1);
-#define L2_CUT(Q)                                       \
-    if (l2_byte<Q>(L.pl) == g) l2_put<Q>(L.pl, L2_NONE); \
-    if (l2_byte<Q>(L.cl) == g) {                         \
-        l2_put<Q>(L.cl, L2_NONE);                        \
-        L.nres--;                                        \
+#define L2_CUT(Q)                                           \
+    if (Q < dmax) {                                         \
+        if (l2_byte<Q>(L.pl) == g) l2_put<Q>(L.pl, L2_NONE); \
+        if (l2_byte<Q>(L.cl) == g) {                         \
+            l2_put<Q>(L.cl, L2_NONE);                        \
+            L.nres--;                                        \
+        }                                                   \
     }
         L2_CUT(0) L2_CUT(1) L2_CUT(2) L2_CUT(3) L2_CUT(4)
 #undef L2_CUT
@@ -89,19 +93,21 @@ __device__ __forceinline__ void l2_evict(LeanLane &L, unsigned long long gone) {
 
 // Node `key` (wave-uniform) takes the free lane `f` (wave-uniform): record, links in both directions.
 __device__ __forceinline__ void l2_adopt(const SparseModel &M, LeanFwdShared &sh, LeanLane &L, uint32_t &ahead, uint32_t key,
-                                         int f) {
+                                         int f, int &dmax) {
     const int lane = threadIdx.x;
     const bool me = lane == f;
     const bool live = L.id != LN_EMPTY;
     // everybody's links TO the new node (needs its id only)
-#define L2_TONEW(Q)                                                   \
-    if (live && Q < (int)L.r.npar && L.r.par[Q] == key) {             \
-        l2_put<Q>(L.pl, (uint32_t)f);                                 \
-        L.pmask |= 1ull << f;                                         \
-    }                                                                 \
-    if (live && Q < (int)L.r.nchi && L.r.chi[Q] == key) {             \
-        l2_put<Q>(L.cl, (uint32_t)f);                                 \
-        L.nres++;                                                     \
+#define L2_TONEW(Q)                                                       \
+    if (Q < dmax) {                                                       \
+        if (live && Q < (int)L.r.npar && L.r.par[Q] == key) {             \
+            l2_put<Q>(L.pl, (uint32_t)f);                                 \
+            L.pmask |= 1ull << f;                                         \
+        }                                                                 \
+        if (live && Q < (int)L.r.nchi && L.r.chi[Q] == key) {             \
+            l2_put<Q>(L.cl, (uint32_t)f);                                 \
+            L.nres++;                                                     \
+        }                                                                 \
     }
     L2_TONEW(0) L2_TONEW(1) L2_TONEW(2) L2_TONEW(3) L2_TONEW(4)
 #undef L2_TONEW
@@ -120,7 +126,7 @@ __device__ __forceinline__ void l2_adopt(const SparseModel &M, LeanFwdShared &sh
     unsigned long long npm = 0ull;
     int nr = 0;
 #define L2_OWN(Q)                                                                              \
-    {                                                                                          \
+    if (Q < np || Q < nc) {                                                                    \
         const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)L.r.par[Q], f);           \
         const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)L.r.chi[Q], f);           \
         const unsigned long long pmk = __ballot(Q < np && L.id == pk);                         \
@@ -143,6 +149,7 @@ __device__ __forceinline__ void l2_adopt(const SparseModel &M, LeanFwdShared &sh
         L.pmask = npm;
         L.nres = nr;
     }
+    dmax = max(dmax, max(np, nc));
     // request the record of its first child for the next position
     if (nc > 0) {
         ahead = (uint32_t)__builtin_amdgcn_readlane((int)L.r.chi[0], f);
@@ -161,7 +168,7 @@ __device__ __forceinline__ unsigned long long l2_need(const LeanLane &L, unsigne
 // caller abandons the column).  One adoption per call, and the caller loops: with the loop in here the compiler
 // keeps the lane state in scratch memory.
 __device__ __forceinline__ bool l2_take_one(const SparseModel &M, LeanFwdShared &sh, LeanLane &L, uint32_t &ahead,
-                                            unsigned long long need) {
+                                            unsigned long long need, int &dmax) {
     const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)need) - 1);
     uint32_t mykey = L.r.chi[4];
     if (3 < (int)L.r.nchi && l2_byte<3>(L.cl) == L2_NONE) mykey = L.r.chi[3];
@@ -172,7 +179,7 @@ __device__ __forceinline__ bool l2_take_one(const SparseModel &M, LeanFwdShared 
     const unsigned long long freem = ~__ballot(L.id != LN_EMPTY);
     if (freem == 0ull) return false;
     const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)freem) - 1);
-    l2_adopt(M, sh, L, ahead, key, f);
+    l2_adopt(M, sh, L, ahead, key, f, dmax);
     return true;
 }
 
@@ -182,10 +189,10 @@ __device__ __forceinline__ unsigned long long l2_children(const LeanLane &L, uns
 }
 
 // sum over the parents of w[q] * value on the parent's lane (the value is 0 on lanes that are not a source)
-__device__ __forceinline__ double l2_parent_sum(const LeanLane &L, double v, bool on) {
+__device__ __forceinline__ double l2_parent_sum(const LeanLane &L, double v, bool on, int dmax) {
     double acc = 0.0;
 #define L2_PAR(Q)                                                \
-    {                                                            \
+    if (Q < dmax) {                                              \
         const uint32_t p = l2_byte<Q>(L.pl);                     \
         const double u = __shfl(v, p == L2_NONE ? 0 : (int)p);   \
         if (on && p != L2_NONE) acc += L.r.par_w[Q] * u;         \
@@ -216,6 +223,7 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
     L.pmask = 0ull;
     L.nres = 0;
     uint32_t ahead = LN_EMPTY;  // node whose record was requested into sh.stage
+    int dmax = 1;               // bound on the degrees seen so far (wave-uniform)
     int E = 0;
     unsigned long long act = 0ull;  // lanes of the active list of the last finished column
     {
@@ -259,6 +267,9 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
                 L2_INIT(0) L2_INIT(1) L2_INIT(2) L2_INIT(3) L2_INIT(4)
 #undef L2_INIT
             }
+            const int deg = lane < n ? max((int)L.r.npar, (int)L.r.nchi) : 0;
+            for (int q = 1; q < ADJ_DEG; q++)
+                if (__ballot(deg > q) != 0ull) dmax = q + 1;
         }
     }
     // record pool slab of this wave (wave-uniform)
@@ -305,7 +316,7 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
             // children of the source lanes that are not in the frontier come in first, one per turn of this loop
             const unsigned long long need = l2_need(L, srcm);
             if (need != 0ull) {
-                if (!l2_take_one(a.M, sh, L, ahead, need)) {
+                if (!l2_take_one(a.M, sh, L, ahead, need, dmax)) {
                     overflow = true;
                     break;
                 }
@@ -319,7 +330,7 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
                 const bool is_act = (act >> lane) & 1ull;
                 // fm, fi (forward.rs:337-388)
                 const double G = lp.p_MM * L.pm + lp.p_IM * L.pi + lp.p_DM * L.pd;
-                const double acc = l2_parent_sum(L, G, is_act);
+                const double acc = l2_parent_sum(L, G, is_act, dmax);
                 if (is_act) {
                     const double pe = L.r.emis == x ? lp.p_match : lp.p_mismatch;
                     L.m = pe * (acc + L.r.init * c_begin);
@@ -329,7 +340,7 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
                 // nodes leave now instead of at the end of the step (one that comes back as a Del-level node is
                 // fetched again), so that a wide frontier still fits the 64 lanes.
                 const unsigned long long resident = __ballot(L.id != LN_EMPTY);
-                if (64 - __popcll(resident) < 16 && (resident & ~act) != 0ull) l2_evict(L, resident & ~act);
+                if (64 - __popcll(resident) < 16 && (resident & ~act) != 0ull) l2_evict(L, resident & ~act, dmax);
                 members = act;
                 srcm = act;
                 lv = lp.p_MD * L.m + lp.p_ID * L.i;
@@ -339,7 +350,7 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
             }
             const bool inS = (S >> lane) & 1ull;
             // (the level value is 0 on every lane outside the previous level's set)
-            const double s = l2_parent_sum(L, lv, inS);
+            const double s = l2_parent_sum(L, lv, inS, dmax);
             const double val = h == 1 ? s + L.r.init * c_del : lp.p_DD * s;
             if (inS) L.d += val;
             lv = inS ? val : 0.0;
@@ -407,7 +418,7 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
         // ---- the column becomes the previous one; nodes that left the frontier free their lanes
         {
             const unsigned long long gone = __ballot(L.id != LN_EMPTY) & ~members;
-            if (gone != 0ull) l2_evict(L, gone);
+            if (gone != 0ull) l2_evict(L, gone, dmax);
         }
         if (member) {
             L.pm = L.m;
