@@ -47,36 +47,85 @@ WORKLOADS = {
                   desc="cfg1m: 5 kb diploid, 10x, L=200, k=16, sparse-adaptive flow (small: tests and rehearsals)"),
     "cfg1": dict(genome=1_000, haplotypes=1, k=16, coverage=10, read_len=200, p=0.001, mode="dense",
                  desc="cfg1: 1 kb haploid, 10x, L=200, k=16, dense forward+backward"),
+    # the reference's own simulation (scripts/sim.sh:184-214, run_n4): draft -k 40 -C 10 -L 10000 -p 0.0003
+    # -U 10000 -N 4 -E 2000 -H 0.01 --H0 0.0002 -P 2 -- tandem repeat of four 10 kb units, 10 kb HiFi reads
+    "rep": dict(tandem=(10000, 4, 0, 0.0002, 1, 2000, 2, 0.01, 0), haplotypes=2, k=40, coverage=10, read_len=10000,
+                p=0.0003, mode="sparse",
+                desc="rep: sim.sh run_n4 shape -- tandem repeat 10 kb unit x 4 (H0=0.0002) + 2 kb unique ends, diploid "
+                     "(H=0.01), 10x of 10 000-base reads (p=0.0003) drawn from the genome, k=40 DBG; generate_mappings"),
+    # the widest frontier among the reference's own test datasets (hmmv2/tests/dbg.rs:73-75: unit 20 bp x 200,
+    # 2 % divergence inside the repeat), scaled to fill a GPU: 200 such loci worth of reads (coverage 4000x)
+    "rep20": dict(tandem=(20, 200, 0, 0.02, 0, 300, 2, 0.02, 0), haplotypes=2, k=40, coverage=400, read_len=1000,
+                  p=0.001, mode="sparse",
+                  desc="rep20: hmmv2/tests/dbg.rs u20n200 -- tandem repeat 20 bp unit x 200 (2 % divergence) + 300 bp "
+                       "ends, diploid (2 %), 400x of 1000-base reads (p=0.001) drawn from the genome, k=40 DBG; "
+                       "generate_mappings"),
 }
+
+
+def cfg_haplotypes(name: str):
+    import dbgphmm_amd as D
+    w = WORKLOADS[name]
+    if "tandem" in w:  # genome.rs:294-340
+        return D.tandem_repeat_polyploid_with_unique_homo_ends(*w["tandem"])
+    hap = D.random_genome(w["genome"], seed=3)
+    return [hap] if w["haplotypes"] == 1 else [hap, D.diverge(hap, 0.01, seed=4)]
 
 
 def cfg_seq_graph(name: str):
     import dbgphmm_amd as D
-    w = WORKLOADS[name]
-    hap = D.random_genome(w["genome"], seed=3)
-    haps = [hap] if w["haplotypes"] == 1 else [hap, D.diverge(hap, 0.01, seed=4)]
-    return D.dbg_from_haplotypes(haps, w["k"])
+    return D.dbg_from_haplotypes(cfg_haplotypes(name), WORKLOADS[name]["k"])
 
 
-def build_workload(name: str, rank: int = 0, world: int = 1, scaling: str = "strong"):
+def build_workload(name: str, rank: int = 0, world: int = 1, scaling: str = "strong", read_len: int = 0):
     """-> (arrays, reads of THIS rank, workload dict).  strong: the one read set of the configuration
-    (seed 1000) cut into `world` contiguous shards balanced on bases; weak: a full read set per rank."""
+    (seed 1000) cut into `world` contiguous shards balanced on bases; weak: a full read set per rank.
+    read_len > 0 overrides the configuration's read length (same coverage: fewer, longer reads)."""
     import dbgphmm_amd as D
     from dbgphmm_amd import dist as PD
-    w = WORKLOADS[name]
+    w = dict(WORKLOADS[name])
+    if read_len > 0 and read_len != w["read_len"]:
+        w["desc"] = w["desc"].replace(f"L={w['read_len']}", f"L={read_len}") + f" [--read-len {read_len}]"
+        w["read_len"] = read_len
     sg = cfg_seq_graph(name)
     param = D.PHMMParams.uniform(w["p"]).with_(n_warmup=w["k"])
     # mapping generation uses the non-zero PHMM (multi_dbg/posterior.rs:616-619); with true copy
     # numbers >= 1 everywhere it equals to_phmm
     arrays = D.vectorised_to_phmm(sg, param, 1 if w["mode"] == "sparse" else 0)
-    total = w["coverage"] * w["genome"] * w["haplotypes"]
-    if scaling == "weak":
-        reads = D.sample_reads(arrays, total, w["read_len"], seed=1000 + rank)
+    if "tandem" in w:
+        # reads are fragments of the GENOME (generate_dataset, e2e.rs:163-232), not walks of the collapsed graph
+        haps = cfg_haplotypes(name)
+
+        def draw(seed):
+            return D.sample_genome_reads(haps, param, w["coverage"], w["read_len"], seed)
     else:
-        reads = D.sample_reads(arrays, total, w["read_len"], seed=1000)
+        total = w["coverage"] * w["genome"] * w["haplotypes"]
+
+        def draw(seed):
+            return D.sample_reads(arrays, total, w["read_len"], seed=seed)
+    if scaling == "weak":
+        reads = draw(1000 + rank)
+    else:
+        reads = draw(1000)
         lo, hi = PD.shard_reads([len(r) for r in reads], world)[rank]
         reads = reads[lo:hi]
     return arrays, reads, w
+
+
+def frontier_profile(rc, mp):
+    """What the last generate_mappings call did on this read set (for the bench line): list lengths, reads that took
+    the rarer routes, dense columns."""
+    from dbgphmm_amd import _ffi
+    cols, flags = rc.last_call_info()
+    cnt = np.diff(mp.arrays()[0].astype(np.int64))
+    n = max(cnt.shape[0], 1)
+    return {"mean_list": float(cnt.mean()) if cnt.size else 0.0, "max_list": int(cnt.max()) if cnt.size else 0,
+            "share_list_gt8": float((cnt > 8).sum()) / n, "share_list_gt16": float((cnt > 16).sum()) / n,
+            "share_list_gt64": float((cnt > 64).sum()) / n,
+            "forced_switch_reads": int(((flags & _ffi.PHMM_READ_FORCED_SWITCH) != 0).sum()),
+            "wide_frontier_reads": int(((flags & _ffi.PHMM_READ_WIDE_FRONTIER) != 0).sum()),
+            "deferred_reads": int(((flags & _ffi.PHMM_READ_DEFERRED) != 0).sum()),
+            "mean_dense_cols": float(cols.mean()) if cols.size else 0.0, "max_dense_cols": int(cols.max()) if cols.size else 0}
 
 
 def cpu_baseline(arrays, reads, mode: str, gpu_logp, gpu_check, budget_s: float = 20.0):
@@ -222,6 +271,7 @@ def main():
     ap.add_argument("--mode", choices=("mapping", "candidates"), default="mapping")
     ap.add_argument("--candidates", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--read-len", type=int, default=0, help="override the workload's read length (e.g. 10000: HiFi)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -261,12 +311,12 @@ def main():
     cand_range = None
     if args.mode == "candidates" and world > 1:
         # 2-D split: candidates first (no reduction), reads only when there are fewer candidates than ranks
-        arrays, all_reads, w = build_workload(args.workload, 0, 1, "strong")
+        arrays, all_reads, w = build_workload(args.workload, 0, 1, "strong", args.read_len)
         grid = PD.shard_grid(args.candidates, [len(r) for r in all_reads], world)
         cand_range, (rlo, rhi) = grid[rank]
         reads = all_reads[rlo:rhi]
     else:
-        arrays, reads, w = build_workload(args.workload, rank, world, args.scaling)
+        arrays, reads, w = build_workload(args.workload, rank, world, args.scaling, args.read_len)
     model = D.PHMMModel(arrays)
     rc = D.ReadCollection(reads)
     n_bases = rc.total_bases()
@@ -391,6 +441,7 @@ def main():
         # the inner loop of `infer` on the mappings just produced: hinted forward score
         # (to_full_prob_reads with mappings, freq.rs:175-192), not part of the timed step
         mp = state["mappings"]
+        extra["frontier"] = frontier_profile(rc, mp)
         model.to_full_prob_reads(rc, mp)
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -9,24 +9,36 @@
 //
 // A node keeps its lane while it stays in the B column; its record (BwdAdj: children, their weights
 // and emissions) and its previous-column values live in that lane's registers.  The entries of the
-// forward record of the position are routed to the lanes of their nodes through LDS; the forward
-// records are prefetched two positions ahead (offset -> header -> arrays), so a step waits for memory
-// only when a node is new to the column (one record fetch).
+// forward record of the position are routed to the lanes of their nodes through LDS.
+//
+// Memory side (round 3; lean_common.h "vector-memory waits"): a wave that walks a read alone must never wait on
+// the one in-order memory counter with a store in front of the load it needs.  So
+//   * the forward records come in by LDS-DMA, the first KB of the record of position pos-3 while pos is computed
+//     (a ring of four 1 KB slots; the offsets of 64 positions are fetched by one load);
+//   * the record of the node the column takes in next -- on a unitig the first parent of the one it took in last
+//     (BwdAdj.par0) -- is requested a position ahead, also into LDS;
+//   * the mapping list of a position is assembled in LDS and leaves as ONE 16-byte-per-lane store; its offsets
+//     are written 64 positions at a time; bases come 64 positions per load;
+//   * every one of these operations is issued from inline asm and counted, every wait is the exact vmcnt(N).
 // Stops, like the generic <64> kernel, at the first position whose nodes do not fit 64 lanes and parks
 // the column in the read's hand-off slot for the 400-slot kernel.
 #pragma once
 
+#include "lds_dma.h"
 #include "lean_common.h"
 #include "sparse_dyn.h"
 
 namespace phmm {
 
+static constexpr int LB_RING = 4;         // forward records in flight / in use
+static constexpr int LB_SLOT = 1024;      // bytes of a record fetched ahead (one 16-byte-per-lane request)
+
 struct LeanBwdShared {
     LeanShared h;
-    // routing of forward-record entries (record slot order) to lanes
-    uint32_t eid[64];
-    double ef[3][64];
-    double etot[64];
+    alignas(16) uint8_t ring[LB_RING][LB_SLOT];  // forward records (record layout, sparse_dyn.h)
+    alignas(16) uint32_t stage[20];              // BwdAdj fetched ahead (80 bytes)
+    alignas(16) uint8_t out[8 + 256 + 512 + 16]; // the mapping record of the position
+    double etot[64];      // totals of the record's entries (B-list selection)
     uint8_t tgt[64];      // lane that received entry j
     uint8_t slot_of[64];  // per lane: record slot of its entry (0xff: none)
 };
@@ -50,13 +62,13 @@ __device__ __forceinline__ void lb_park(const SparseBwdArgs &a, uint32_t gi, boo
     }
 }
 
-__global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArgs a) {
+__global__ void __launch_bounds__(64, 3) lean_backward_kernel(const SparseBwdArgs a) {
     __shared__ LeanBwdShared sh;
     const int lane = threadIdx.x;
     const uint32_t gi = a.lanes[blockIdx.x];
     const int g = (int)(gi / a.W), r = (int)(gi % a.W);
-    const int len = a.d.len[gi];
-    const int s0 = a.sw[gi];
+    const int len = __builtin_amdgcn_readfirstlane(a.d.len[gi]);
+    const int s0 = __builtin_amdgcn_readfirstlane(a.sw[gi]);
     const uint64_t p0 = a.lane_pos0[gi];
     const uint64_t q0 = a.map_pos0[gi];
     const double logP = a.d.logPf[gi];
@@ -65,6 +77,7 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
     const int kP = ok ? (int)rint(-logP / SP_LN2) : 0;
     const double cP = ok ? exp(-logP - (double)kP * SP_LN2) : 0.0;
     uint32_t err = 0;
+    int vm_issued = 0;  // vector-memory operations issued from inline asm so far (wave-uniform)
 
     // ---- lane state: node, record, B values of the column of position pos+1
     uint32_t id = LN_EMPTY;
@@ -79,24 +92,18 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
     bool stopped = false;
     int stop_at = 0;
 
-    // mapping-pool slab of this wave
+    // ---- mapping records: slab of this wave, offsets of the positions done (lane j: position mo_hi - j)
     unsigned long long slab = 0ull, slab_end = 0ull;
-    auto map_alloc = [&](uint64_t bytes) -> uint8_t * {
-        if (slab + bytes > slab_end) {
-            unsigned long long o = 0;
-            if (lane == 0) o = atomicAdd(a.mpool.top, (unsigned long long)LN_SLAB);
-            slab = __shfl(o, 0);
-            slab_end = slab + LN_SLAB;
-        }
-        if (slab_end > a.mpool.cap) return nullptr;
-        uint8_t *p = a.mpool.base + slab;
-        slab += bytes;
-        return p;
+    unsigned long long mofv = 0ull, mofm = 0ull;
+    int mo_hi = 0;
+    auto flush_map_offsets = [&]() {
+        if ((mofm >> lane) & 1ull) vm_store8(&a.mpool.off[q0 + (uint64_t)(mo_hi - lane)], mofv);
+        vm_issued++;
+        mofm = 0ull;
     };
-    // to_mapping_by_score_ratio of the values on the lanes (has: lane carries an entry; slot: its record
-    // slot): kept = val > 0 and within the ratio of the best, sorted descending, equal values by node id
-    auto emit = [&](uint64_t pos_index, bool has, uint32_t nid, double val, int slot) -> bool {
-        (void)slot;
+    // to_mapping_by_score_ratio of the values on the lanes (has: lane carries an entry): kept = val > 0 and within
+    // the ratio of the best, sorted descending, equal values by node id
+    auto emit = [&](int p, bool has, uint32_t nid, double val) -> bool {
         const double v = has ? val : 0.0;
         const double p0v = wave_max(v);
         const bool keep = has && v > 0.0 && v > p0v * a.ratio_lin;
@@ -118,77 +125,161 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
             const uint32_t un = (uint32_t)__builtin_amdgcn_readlane((int)nid, l);
             rank += (u > lv) || (u == lv && un < nid);
         }
-        const uint64_t idb = (uint64_t)((k + 1) & ~1) * 4;
-        const uint64_t bytes = (8 + idb + (uint64_t)k * 8 + 15) & ~15ull;
-        uint8_t *rec = map_alloc(bytes);
-        if (!rec) return false;
+        const uint32_t idb = (uint32_t)((k + 1) & ~1) * 4;
+        const uint32_t raw = 8 + idb + (uint32_t)k * 8;
+        const uint32_t bytes = (raw + 15) & ~15u;
+        if (slab + bytes > slab_end) {
+            unsigned long long o = 0;
+            if (lane == 0) o = atomicAdd(a.mpool.top, (unsigned long long)LN_SLAB);
+            o = __shfl(o, 0);
+            slab = (o + 15ull) & ~15ull;  // (other writers of this pool allocate multiples of 8)
+            slab_end = o + LN_SLAB;
+        }
+        if (slab_end > a.mpool.cap) return false;
+        uint8_t *rec = a.mpool.base + slab;
+        if (mofm != 0ull && p < mo_hi - 63) flush_map_offsets();
+        if (mofm == 0ull) mo_hi = p;
+        if (lane == mo_hi - p) mofv = slab + 8;
+        mofm |= 1ull << (mo_hi - p);
+        slab += bytes;
         if (lane == 0) {
-            ((uint32_t *)rec)[0] = (uint32_t)k;
-            ((uint32_t *)rec)[1] = 0;
-            a.mpool.off[pos_index] = (uint64_t)(rec - a.mpool.base) + 8;
+            *(unsigned long long *)sh.out = (unsigned long long)(uint32_t)k;
+            if (k & 1) *(uint32_t *)(sh.out + 8 + 4 * k) = 0u;
+            if (raw != bytes) *(unsigned long long *)(sh.out + raw) = 0ull;
         }
         if (keep) {
-            ((uint32_t *)(rec + 8))[rank] = nid;
-            ((double *)(rec + 8 + idb))[rank] = lv;
+            *(uint32_t *)(sh.out + 8 + 4 * rank) = nid;
+            *(double *)(sh.out + 8 + idb + 8 * rank) = lv;
         }
+        wave_sync();
+        if (lane < (int)(bytes >> 4)) vm_store16(rec + lane * 16, *(const u32x4 *)(sh.out + lane * 16));
+        vm_issued++;
+        wave_sync();
         return true;
     };
 
-    // ---- forward records, prefetched: (header of pos-2, arrays of pos-1) are in flight while pos is computed
-    auto rec_ptr = [&](int p) -> const uint8_t * {  // record of position p (nullptr: none)
-        if (p < 0) return nullptr;
-        const uint64_t o1 = a.fpool.off[p0 + (uint64_t)p];
-        return o1 ? a.fpool.base + (o1 - 8) : nullptr;
+    // ---- forward records.  Offsets of 64 positions per load (lane j: position fo_hi - j); the first KB of a record
+    // by LDS-DMA into ring slot (position & 3); rqv: vm_issued right after the request of a slot
+    unsigned long long fofv = 0ull;
+    int fo_hi = -1, fo_lo = 0;  // positions [fo_lo, fo_hi] are on the lanes
+    int rqv = 0;        // lane (p & 3): vm_issued right after the request of the record of position p
+    int next_req = -1;  // highest position whose record has not been requested
+    auto request = [&](int p) {  // p >= s0, wave-uniform
+        if (p > fo_hi || p < fo_lo) {
+            const int q = p - lane;
+            unsigned long long o = q >= s0 ? a.fpool.off[p0 + (uint64_t)q] : 0ull;
+            fofv = (unsigned long long)(uint32_t)vm_settle((int)(uint32_t)o) |
+                   ((unsigned long long)(uint32_t)vm_settle((int)(uint32_t)(o >> 32)) << 32);
+            fo_hi = p;
+            fo_lo = p - 63 > s0 ? p - 63 : s0;
+        }
+        const int j = fo_hi - p;
+        const unsigned long long o1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fofv >> 32), j) << 32) |
+                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fofv, j);
+        if (o1 != 0ull) {
+            glds16(a.fpool.base + (o1 - 8) + (size_t)lane * 16,
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)sh.ring[p & (LB_RING - 1)]));
+            vm_issued++;
+        } else if (lane == 0) {
+            *(uint32_t *)sh.ring[p & (LB_RING - 1)] = 0xffffffffu;  // no record: reads as "does not fit"
+        }
+        if (lane == (p & (LB_RING - 1))) rqv = vm_issued;
+        next_req = p - 1;
     };
     struct Hdr {
-        const uint8_t *rec;
+        bool present;
         int n, na, E;
     };
-    auto load_hdr = [&](int p) -> Hdr {
-        Hdr h{rec_ptr(p), 0, 0, 0};
-        if (h.rec) {
-            const int *hw = (const int *)h.rec;
-            h.n = hw[0];
-            h.na = hw[1];
-            h.E = hw[2];
-        }
+    // the record of position p is in its ring slot (waits for its request)
+    auto header = [&](int p) -> Hdr {
+        vm_wait_upto(vm_issued - __builtin_amdgcn_readlane(rqv, p & (LB_RING - 1)));
+        wave_sync();
+        const int *hw = (const int *)sh.ring[p & (LB_RING - 1)];
+        Hdr h;
+        h.n = __builtin_amdgcn_readfirstlane(hw[0]);
+        h.na = __builtin_amdgcn_readfirstlane(hw[1]);
+        h.E = __builtin_amdgcn_readfirstlane(hw[2]);
+        h.present = h.n != -1;
         return h;
     };
     struct Ent {
         uint32_t id;
         double m, i, d;
     };
-    auto load_ent = [&](const Hdr &h) -> Ent {
+    // entry `slot` of the record of position p (header h): from the ring, or from memory where the record is longer
+    // than a ring slot (more than ~40 nodes: rare)
+    auto entry = [&](int p, const Hdr &h, int slot, bool want) -> Ent {
         Ent e{LN_EMPTY, 0.0, 0.0, 0.0};
-        if (h.rec && h.n <= 64 && lane < h.n) {
-            const uint64_t idb = (uint64_t)((h.n + 1) & ~1) * 4;
-            const uint32_t *ids = (const uint32_t *)(h.rec + 16);
-            const double *fm = (const double *)(h.rec + 16 + idb), *fi = fm + h.na, *fd = fi + h.na;
-            e.id = ids[lane];
-            e.d = fd[lane];
-            e.m = lane < h.na ? fm[lane] : 0.0;
-            e.i = lane < h.na ? fi[lane] : 0.0;
+        const uint32_t idb = (uint32_t)((h.n + 1) & ~1) * 4;
+        const uint32_t om = 16 + idb, oi = om + 8 * (uint32_t)h.na, od = oi + 8 * (uint32_t)h.na;
+        const uint32_t bytes = od + 8 * (uint32_t)h.n;
+        if (bytes <= (uint32_t)LB_SLOT) {
+            if (want) {
+                const uint8_t *rec = sh.ring[p & (LB_RING - 1)];
+                e.id = *(const uint32_t *)(rec + 16 + 4 * slot);
+                e.d = *(const double *)(rec + od + 8 * slot);
+                if (slot < h.na) {
+                    e.m = *(const double *)(rec + om + 8 * slot);
+                    e.i = *(const double *)(rec + oi + 8 * slot);
+                }
+            }
+        } else {
+            const unsigned long long o1 = a.fpool.off[p0 + (uint64_t)p];
+            const uint8_t *rec = a.fpool.base + (o1 - 8);
+            if (want) {
+                e.id = *(const uint32_t *)(rec + 16 + 4 * slot);
+                e.d = *(const double *)(rec + od + 8 * slot);
+                if (slot < h.na) {
+                    e.m = *(const double *)(rec + om + 8 * slot);
+                    e.i = *(const double *)(rec + oi + 8 * slot);
+                }
+            }
+            vm_drain();
         }
         return e;
     };
 
-    Hdr hcur{}, hnext{};
-    Ent ecur{}, enext{};
+    // ---- bases, 64 positions per load (lane j: position xb_hi - j)
+    int xb = 0, xb_hi = -1;
+    auto load_bases = [&](int from) {
+        const int p = from - lane;
+        const int b = p >= 0 ? (int)a.bases[((size_t)g * a.Lb + p) * a.W + r] : 0;
+        xb = vm_settle(b);
+        xb_hi = from;
+    };
+    // ---- the BwdAdj fetched ahead
+    uint32_t ahead = LN_EMPTY;
+    int rq_adj = 0;
+    auto request_adj = [&](uint32_t node) {
+        ahead = node;
+        if (node != LN_EMPTY) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a record just read out of sh.stage is in registers)
+            if (lane < 5)
+                glds16((const uint8_t *)&a.M.badj[node] + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)sh.stage));
+            vm_issued++;
+            rq_adj = vm_issued;
+        }
+    };
+
+    Hdr hcur{};
     if (a.mode == 0) {
         pos = len - 1;
         prev_is_init = true;
         // merged index len: F.tables[len-1] (.) b_init / P   (table.rs:414-434, backward.rs:197-211)
-        hcur = load_hdr(len - 1);
-        if (!hcur.rec || hcur.n > 64) {
+        request(len - 1);
+        if (len - 2 >= s0) request(len - 2);
+        if (len - 3 >= s0) request(len - 3);
+        hcur = header(len - 1);
+        if (!hcur.present || hcur.n > 64) {
             stopped = true;  // does not fit this class (or missing): nothing done
             stop_at = len;
         } else {
-            ecur = load_ent(hcur);
+            const Ent e = entry(len - 1, hcur, lane, lane < hcur.n);
             const double w = ok ? exp((double)hcur.E * SP_LN2 - logP) * lp.p_end : 0.0;
-            if (!emit(q0 + (uint64_t)(len - 1), lane < hcur.n, ecur.id, w * (ecur.m + ecur.i + ecur.d), lane)) err |= SP_ERR_POOL;
+            if (!emit(len - 1, lane < hcur.n, e.id, w * (e.m + e.i + e.d))) err |= SP_ERR_POOL;
         }
     } else {
-        pos = a.stop[gi];
+        pos = __builtin_amdgcn_readfirstlane(a.stop[gi]);
         if (pos < len - 1) {
             const BHandoff &h = a.hand[gi];
             if (h.n > 64) {
@@ -209,13 +300,13 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         } else {
             prev_is_init = true;
         }
+        if (!stopped && pos >= s0 + 1) {
+            request(pos - 1);
+            if (pos - 2 >= s0) request(pos - 2);
+        }
     }
-    if (!stopped && !err && pos >= s0 + 1) {
-        hcur = load_hdr(pos - 1);
-        ecur = load_ent(hcur);
-        hnext = load_hdr(pos - 2 >= s0 ? pos - 2 : -1);
-    }
-    uint8_t xn = (!stopped && !err && pos >= s0 + 1) ? a.bases[((size_t)g * a.Lb + pos) * a.W + r] : (uint8_t)0;
+    if (!stopped && !err && pos >= s0 + 1) load_bases(pos);
+    vm_drain();  // everything the prologue loaded has arrived: no compiler-placed vmcnt wait inside the position loop
 
 #ifdef PHMM_LEAN_PROF
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = 0;
@@ -234,21 +325,22 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         pc0 = clock64();
         psteps++;
 #endif
-        const uint8_t x = xn;
-        if (pos - 1 >= s0 + 1) xn = a.bases[((size_t)g * a.Lb + pos - 1) * a.W + r];
-        // this position's record is (hcur, ecur); start the next one's arrays and the header after it
-        enext = load_ent(hnext);
-        const Hdr hnn = load_hdr(pos - 3 >= s0 ? pos - 3 : -1);
-        if (!hcur.rec || hcur.n > 64) {
+        if (xb_hi - pos >= 64) load_bases(pos);
+        const uint8_t x = (uint8_t)__builtin_amdgcn_readlane(xb, xb_hi - pos);
+        // this position's record is that of pos-1 (requested two positions ago); start the one of pos-3
+        if (next_req >= s0 && next_req >= pos - 3) request(next_req);
+        hcur = header(pos - 1);
+        if (!hcur.present || hcur.n > 64) {
             stopped = true;  // the forward record is larger than this class
             stop_at = pos;
             break;
         }
         const int n = hcur.n, na = hcur.na < hcur.n ? hcur.na : hcur.n;
+        const bool has_e = lane < n;
+        const Ent ecur = entry(pos - 1, hcur, lane, has_e);
         PROFB_T(0)
         // ---- route the entries to the lanes of their nodes
         ln_rebuild(sh.h, id);
-        const bool has_e = lane < n;
         int tl = has_e ? ln_find(sh.h, ecur.id) : -1;
         const bool miss = has_e && tl < 0;
         const unsigned long long missm = __ballot(miss);
@@ -266,10 +358,6 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
             tl = __ffsll((long long)f) - 1;
         }
         if (has_e) {
-            sh.eid[lane] = ecur.id;
-            sh.ef[0][lane] = ecur.m;
-            sh.ef[1][lane] = ecur.i;
-            sh.ef[2][lane] = ecur.d;
             sh.etot[lane] = ecur.m + ecur.i + ecur.d;
             sh.tgt[lane] = (uint8_t)tl;
         }
@@ -279,27 +367,43 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         ln_sync();
         const int slot = sh.slot_of[lane] == 0xff ? -1 : (int)sh.slot_of[lane];
         PROFB_T(1)
-        double fm = 0.0, fi = 0.0, fd = 0.0;
+        const Ent mine = entry(pos - 1, hcur, slot < 0 ? 0 : slot, slot >= 0);
+        const double fm = mine.m, fi = mine.i, fd = mine.d;
         bool sel = false;  // member of the B list: one of the `na` largest totals (ties: record order)
-        if (slot >= 0) {
-            fm = sh.ef[0][slot];
-            fi = sh.ef[1][slot];
-            fd = sh.ef[2][slot];
-            if (id == LN_EMPTY) {
-                // new to the column: take the node and fetch its record
-                id = sh.eid[slot];
-                R = a.M.badj[id];
-                pm = pi = pd = 0.0;
-                inprev = false;
-                // make it findable for the child links below
-                uint32_t h = ln_hash(id);
-                for (;;) {
-                    const uint32_t old = atomicCAS(&sh.h.ent[h].x, LN_EMPTY, id);
-                    if (old == LN_EMPTY) break;
-                    h = (h + 1) & (LN_HASH - 1);
+        // ---- nodes new to the column take their lanes; the record of ONE new node that was foreseen comes out of LDS,
+        // anything else from memory (then every memory operation of the wave is waited for)
+        {
+            const bool isnew = slot >= 0 && id == LN_EMPTY;
+            const unsigned long long newm = __ballot(isnew);
+            if (newm != 0ull) {
+                const int l1 = __builtin_amdgcn_readfirstlane(__ffsll((long long)newm) - 1);
+                const uint32_t key1 = (uint32_t)__builtin_amdgcn_readlane((int)mine.id, l1);
+                const bool foreseen = (newm & (newm - 1ull)) == 0ull && key1 == ahead;
+                if (foreseen) {
+                    vm_wait_upto(vm_issued - rq_adj);
+                    if (isnew) R = *(const BwdAdj *)sh.stage;
+                } else {
+                    if (isnew) R = a.M.badj[mine.id];
+                    vm_drain();
                 }
-                sh.h.ent[h].y = (uint32_t)lane;
+                if (isnew) {
+                    id = mine.id;
+                    pm = pi = pd = 0.0;
+                    inprev = false;
+                    // make it findable for the child links below
+                    uint32_t h = ln_hash(id);
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&sh.h.ent[h].x, LN_EMPTY, id);
+                        if (old == LN_EMPTY) break;
+                        h = (h + 1) & (LN_HASH - 1);
+                    }
+                    sh.h.ent[h].y = (uint32_t)lane;
+                }
+                // the node expected next: the first parent of the (first) one that came in
+                request_adj((uint32_t)__builtin_amdgcn_readlane((int)R.par0, l1));
             }
+        }
+        if (slot >= 0) {
             if (na >= n) sel = true;
             else {
                 const double t = sh.etot[slot];
@@ -403,7 +507,7 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         const double w = !ok ? 0.0 : ((ew > -1000 && ew < 1000) ? cP * sp_pow2(ew) : exp((double)(hcur.E + Ecur) * SP_LN2 - logP));
         const double val = (slot >= 0 && sel) ? w * (fm * bm + fi * bi + fd * bd) : 0.0;
         PROFB_T(5)
-        if (!emit(q0 + (uint64_t)(pos - 1), slot >= 0, id, val, slot)) {
+        if (!emit(pos - 1, slot >= 0, id, val)) {
             err |= SP_ERR_POOL;
             break;
         }
@@ -421,9 +525,6 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         Eprev = Ecur;
         prev_is_init = false;
         have_col = true;
-        hcur = hnext;
-        ecur = enext;
-        hnext = hnn;
         PROFB_T(6)
     }
 #ifdef PHMM_LEAN_PROF
@@ -432,6 +533,8 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
                psteps, pt[0] / psteps, pt[1] / psteps, pt[2] / psteps, pt[3] / psteps, pt[4] / psteps, pt[5] / psteps,
                pt[6] / psteps);
 #endif
+    if (mofm != 0ull) flush_map_offsets();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no fetch-ahead may outlive the wave's use of LDS
     // ---- leave: park the column for the next phase, or hand it to the dense backward kernel
     if (stopped && !err) {
         if (have_col && stop_at < len) lb_park(a, gi, inprev, id, pm, pi, pd, Eprev);

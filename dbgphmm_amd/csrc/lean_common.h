@@ -17,6 +17,50 @@ struct LeanShared {
 
 __device__ __forceinline__ void ln_sync() { wave_sync(); }
 
+// ---- vector-memory waits of the frontier kernels.
+// gfx950 counts loads, stores and LDS-DMA on ONE in-order counter (vmcnt): waiting for a load also waits for every
+// older store, and hipcc, which cannot know how many stores a loop iteration issued behind a load that is still in
+// flight at the back edge, waits with vmcnt(0) -- a wave that walks a read alone then sits out one store round trip
+// to HBM (~1 us) per read position.  The frontier kernels therefore issue the memory operations of their
+// position loop from inline asm (one 16-byte store instruction per record, requests for the next records straight
+// into LDS), count them in a wave-uniform integer, and wait with the exact vmcnt(N) for the one operation they
+// need.  Operations the compiler issues on rare paths are not counted: N is then smaller than the true distance
+// and the wait is merely conservative.
+__device__ __forceinline__ void vm_wait_upto(int n) {
+    // n: operations issued AFTER the one waited for (wave-uniform)
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+// 16 bytes per lane to global memory, invisible to the compiler's counter model (see above); exec-masked by the caller
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// (a store of more than 8 bytes reads its data registers over two passes: a VALU write to them in the next slot can
+// overtake the second -- hipcc pads that hazard for its own stores, not for inline asm.  Found the hard way: one
+// low dword in 10^7 mapping entries changed from run to run.)
+__device__ __forceinline__ void vm_store16(void *dst, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void vm_store8(void *dst, unsigned long long v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+}
+// every vector-memory operation of the wave has completed, and the compiler knows it (a real S_WAITCNT: vmcnt 0,
+// expcnt / lgkmcnt untouched) -- behind a load on a rare path, so that the registers it wrote are not waited for
+// again, with vmcnt(0), at every later use on EVERY path
+__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0f70); }
+// a value that a (compiler-visible) load has just delivered: consumed HERE, so that the load's wait is placed here
+// and not at a later join, where it would be a vmcnt(0) on every path
+__device__ __forceinline__ int vm_settle(int v) {
+    int o;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(v));
+    return o;
+}
+
 __device__ __forceinline__ uint32_t ln_hash(uint32_t id) { return (id * 2654435761u) >> 24; }
 
 // lane of node `id` or -1

@@ -60,7 +60,11 @@ static_assert(sizeof(FwdAdj) == 96, "six 16-byte pieces are fetched ahead");
 // that entered before it.
 struct LeanFwdShared {
     alignas(16) uint32_t stage[32];  // 96 bytes used (read back as one FwdAdj: 16-byte LDS reads)
+    // the column's record, assembled here and written out 16 bytes per lane (one store instruction up to 1 KB):
+    // header 16 + ids 256 + m, i, d 3 x 512
+    alignas(16) uint8_t rec[16 + 256 + 3 * 512];
 };
+static constexpr int LEAN_REC_MAX = 16 + 256 + 3 * 512;
 
 // a wave-uniform double, told to the compiler (kept in scalar registers)
 __device__ __forceinline__ double l2_uniform(double v) {
@@ -92,8 +96,9 @@ __device__ __forceinline__ void l2_evict(LeanLane &L, unsigned long long gone, i
 }
 
 // Node `key` (wave-uniform) takes the free lane `f` (wave-uniform): record, links in both directions.
+// `vm_after`: vector-memory operations this wave has issued since its last request into sh.stage (lean_common.h)
 __device__ __forceinline__ void l2_adopt(const SparseModel &M, LeanFwdShared &sh, LeanLane &L, uint32_t &ahead, uint32_t key,
-                                         int f, int &dmax) {
+                                         int f, int &dmax, int &vm_after) {
     const int lane = threadIdx.x;
     const bool me = lane == f;
     const bool live = L.id != LN_EMPTY;
@@ -113,10 +118,11 @@ __device__ __forceinline__ void l2_adopt(const SparseModel &M, LeanFwdShared &sh
 #undef L2_TONEW
     // its record: requested a position ahead, or fetched now
     if (key == ahead) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vm_wait_upto(vm_after);
         if (me) L.r = *(const FwdAdj *)sh.stage;
-    } else if (me) {
-        L.r = M.fadj[key];
+    } else {
+        if (me) L.r = M.fadj[key];
+        vm_drain();
     }
     // (a free lane holds zeros: pm, pi, pd since it was freed, m, i, d since the step began)
     if (me) L.id = key;
@@ -153,8 +159,10 @@ __device__ __forceinline__ void l2_adopt(const SparseModel &M, LeanFwdShared &sh
     // request the record of its first child for the next position
     if (nc > 0) {
         ahead = (uint32_t)__builtin_amdgcn_readlane((int)L.r.chi[0], f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the record just read out of sh.stage is in registers
         if (lane < 6)
             glds16((const uint8_t *)&M.fadj[ahead] + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)sh.stage));
+        vm_after = 0;
     }
 }
 
@@ -168,7 +176,7 @@ __device__ __forceinline__ unsigned long long l2_need(const LeanLane &L, unsigne
 // caller abandons the column).  One adoption per call, and the caller loops: with the loop in here the compiler
 // keeps the lane state in scratch memory.
 __device__ __forceinline__ bool l2_take_one(const SparseModel &M, LeanFwdShared &sh, LeanLane &L, uint32_t &ahead,
-                                            unsigned long long need, int &dmax) {
+                                            unsigned long long need, int &dmax, int &vm_after) {
     const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)need) - 1);
     uint32_t mykey = L.r.chi[4];
     if (3 < (int)L.r.nchi && l2_byte<3>(L.cl) == L2_NONE) mykey = L.r.chi[3];
@@ -179,7 +187,7 @@ __device__ __forceinline__ bool l2_take_one(const SparseModel &M, LeanFwdShared 
     const unsigned long long freem = ~__ballot(L.id != LN_EMPTY);
     if (freem == 0ull) return false;
     const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)freem) - 1);
-    l2_adopt(M, sh, L, ahead, key, f, dmax);
+    l2_adopt(M, sh, L, ahead, key, f, dmax, vm_after);
     return true;
 }
 
@@ -207,14 +215,15 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
     const int lane = threadIdx.x;
     const uint32_t gi = a.lanes[blockIdx.x];
     const int g = (int)(gi / a.W), r = (int)(gi % a.W);
-    const int len = a.d.len[gi];
+    const int len = __builtin_amdgcn_readfirstlane(a.d.len[gi]);
     const uint64_t p0 = a.lane_pos0[gi];
     const LinParams &lp = a.M.lp;
     uint32_t err = 0;
-    int pos = a.stop[gi];  // first position to compute
+    int pos = __builtin_amdgcn_readfirstlane(a.stop[gi]);  // first position to compute
     int done_to = pos;
     int end = len;
     if (a.max_steps > 0 && pos + a.max_steps < len) end = pos + a.max_steps;
+    int vm_after = 0;  // see lean_common.h: vector-memory waits
 
     LeanLane L;
     L.id = LN_EMPTY;
@@ -277,7 +286,25 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
     // InsBegin of the previous column in that column's scale (fib, forward.rs:541-545); afterwards it is
     // carried along with the exact power-of-two rescales
     double ibs = l2_uniform((!err && pos < end) ? exp(a.M.logib[pos - 1] - (double)E * SP_LN2) : 0.0);
-    uint8_t xn = (!err && pos < end) ? a.bases[((size_t)g * a.Lb + pos) * a.W + r] : (uint8_t)0;
+    // The read's bases, 64 positions per load: lane j holds the base of position xb0 + j.  (One load per position
+    // would be one more wait per position, and every wait on a load is a wait on the stores before it.)
+    int xb = 0, xb0 = pos;
+    auto load_bases = [&](int from) {
+        const int p = from + lane;
+        const int b = p < a.Lb ? (int)a.bases[((size_t)g * a.Lb + p) * a.W + r] : 0;
+        xb = vm_settle(b);
+        xb0 = from;
+    };
+    if (!err && pos < end) load_bases(pos);
+    vm_drain();  // everything the prologue loaded has arrived: no compiler-placed vmcnt wait inside the position loop
+    // record offsets of the positions done, lane j: position (ob0 + j); written 64 at a time
+    unsigned long long offv = 0ull, offm = 0ull;
+    int ob0 = pos & ~63;
+    auto flush_offsets = [&]() {
+        if ((offm >> lane) & 1ull) vm_store8(&a.pool.off[p0 + (uint64_t)(ob0 + lane)], offv);
+        vm_after++;
+        offm = 0ull;
+    };
 
 #ifdef PHMM_LEAN_PROF
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = 0;
@@ -296,8 +323,8 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
         pc0 = clock64();
         psteps++;
 #endif
-        const uint8_t x = xn;
-        if (pos + 1 < end) xn = a.bases[((size_t)g * a.Lb + pos + 1) * a.W + r];
+        if (pos - xb0 >= 64) load_bases(pos);
+        const uint8_t x = (uint8_t)__builtin_amdgcn_readlane(xb, pos - xb0);
         // ---- top = previous nodes within the ratio of the best total (table.rs:134-149)
         const double t = L.id != LN_EMPTY ? L.pm + L.pi + L.pd : 0.0;
         const double tmax = l2_uniform(wave_max(t));
@@ -316,7 +343,7 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
             // children of the source lanes that are not in the frontier come in first, one per turn of this loop
             const unsigned long long need = l2_need(L, srcm);
             if (need != 0ull) {
-                if (!l2_take_one(a.M, sh, L, ahead, need, dmax)) {
+                if (!l2_take_one(a.M, sh, L, ahead, need, dmax, vm_after)) {
                     overflow = true;
                     break;
                 }
@@ -376,12 +403,14 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
         E += e;
         ibs = l2_uniform(ib_cur * sc);
         PROF_T(5)
-        // ---- store the column: active entries first, then the Del-only ones
+        // ---- store the column: active entries first, then the Del-only ones.  The record is assembled in LDS and
+        // leaves as 16 bytes per lane: one store instruction (two beyond 1 KB), counted in vm_after
         {
             const int na = __popcll(act);
             const int n = __popcll(members);
-            const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
-            const uint64_t bytes = (16 + idb + (uint64_t)(2 * na + n) * 8 + 15) & ~15ull;
+            const uint32_t idb = (uint32_t)((n + 1) & ~1) * 4;
+            const uint32_t raw = 16 + idb + (uint32_t)(2 * na + n) * 8;
+            const uint32_t bytes = (raw + 15) & ~15u;
             if (slab + bytes > slab_end) {
                 unsigned long long o = 0;
                 if (lane == 0) o = atomicAdd(a.pool.top, (unsigned long long)LN_SLAB);
@@ -393,27 +422,37 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
                 break;
             }
             uint8_t *rec = a.pool.base + slab;
-            if (lane == 0) {
-                ((uint32_t *)rec)[0] = (uint32_t)n;
-                ((uint32_t *)rec)[1] = (uint32_t)na;
-                ((int *)rec)[2] = E;
-                ((uint32_t *)rec)[3] = 0;
-                a.pool.off[p0 + (uint64_t)pos] = slab + 8;
-            }
+            if ((pos & 63) == 0 && offm != 0ull) flush_offsets();
+            if (offm == 0ull) ob0 = pos & ~63;
+            if (lane == (pos & 63)) offv = slab + 8;
+            offm |= 1ull << (pos & 63);
             slab += bytes;
+            if (lane == 0) {
+                *(u32x4 *)sh.rec = u32x4{(uint32_t)n, (uint32_t)na, (uint32_t)E, 0u};
+                if (n & 1) *(uint32_t *)(sh.rec + 16 + 4 * n) = 0u;    // the pads are zero, not leftovers
+                if (raw != bytes) *(unsigned long long *)(sh.rec + raw) = 0ull;
+            }
             if (member) {
                 const unsigned long long below = (1ull << lane) - 1ull;
                 const bool isa = (act >> lane) & 1ull;
                 const int slot = isa ? __popcll(act & below) : na + __popcll(members & ~act & below);
-                uint32_t *ids = (uint32_t *)(rec + 16);
-                double *om = (double *)(rec + 16 + idb), *oi = om + na, *od = oi + na;
-                ids[slot] = L.id;
-                od[slot] = L.d;
+                uint8_t *vals = sh.rec + 16 + idb;
+                *(uint32_t *)(sh.rec + 16 + 4 * slot) = L.id;
+                *(double *)(vals + (size_t)(2 * na + slot) * 8) = L.d;
                 if (isa) {
-                    om[slot] = L.m;
-                    oi[slot] = L.i;
+                    *(double *)(vals + (size_t)slot * 8) = L.m;
+                    *(double *)(vals + (size_t)(na + slot) * 8) = L.i;
                 }
             }
+            wave_sync();
+            const int nchunk = (int)(bytes >> 4);
+            if (lane < nchunk) vm_store16(rec + lane * 16, *(const u32x4 *)(sh.rec + lane * 16));
+            vm_after++;
+            if (nchunk > 64) {
+                if (lane + 64 < nchunk) vm_store16(rec + (lane + 64) * 16, *(const u32x4 *)(sh.rec + (lane + 64) * 16));
+                vm_after++;
+            }
+            wave_sync();  // (the next column is assembled over this one)
         }
         // ---- the column becomes the previous one; nodes that left the frontier free their lanes
         {
@@ -433,6 +472,7 @@ __global__ void __launch_bounds__(64, 4) lean_forward_kernel(const SparseFwdArgs
         printf("lean_fwd prof: steps %d | top %lld take-in %lld children %lld fm %lld del %lld rescale %lld store %lld (cycles/step)\n", psteps,
                pt[0] / psteps, pt[1] / psteps, pt[3] / psteps, pt[2] / psteps, pt[4] / psteps, pt[5] / psteps, pt[6] / psteps);
 #endif
+    if (offm != 0ull) flush_offsets();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no fetch-ahead may outlive the wave's use of LDS
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
     const bool finished = !err && done_to >= len;

@@ -251,6 +251,7 @@ void model_upload(phmm_model *m) {
         f.nchi = b.nchi = (uint8_t)std::min<uint32_t>(nc, ADJ_DEG);
         f.emis = b.emis = m->emission[v];
         f.init = ilin[v];
+        b.par0 = np > 0 ? m->par_node[m->par_off[v]] : 0xffffffffu;
         for (uint32_t q = 0; q < (uint32_t)ADJ_DEG; q++) {
             f.par[q] = f.chi[q] = b.chi[q] = 0xffffffffu;
             if (q < f.npar) {

@@ -192,7 +192,7 @@ struct alignas(16) BwdAdj {   // backward: sums over children
     uint32_t chi[ADJ_DEG];
     uint8_t chi_emis[ADJ_DEG];
     uint8_t emis, nchi, over;
-    uint32_t pad;
+    uint32_t par0;            // first parent (0xffffffff: none): the node a backward column takes in next on a unitig
 };
 // Topology-only record of the hinted forward (candidate batches bring their own init / trans): parents with the
 // ids of their edges, so that trans[candidate][edge] is one dependent load behind the record.

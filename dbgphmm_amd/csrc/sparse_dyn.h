@@ -31,7 +31,7 @@ __device__ __forceinline__ uint64_t pool_alloc(const RecPool &p, uint64_t bytes)
 template <int CAP> __device__ bool store_record(const RecPool &p, uint64_t pos_index, const FVec<CAP> &c) {
     const int n = c.n, na = c.na;
     const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
-    const uint64_t bytes = 16 + idb + (uint64_t)(2 * na + n) * 8;
+    const uint64_t bytes = (16 + idb + (uint64_t)(2 * na + n) * 8 + 15) & ~15ull;  // records start 16-byte aligned (LDS-DMA reads)
     const uint64_t o = pool_alloc(p, bytes);
     if (o + bytes > p.cap) return false;
     uint8_t *rec = p.base + o;
@@ -59,7 +59,7 @@ template <int CAP> __device__ bool store_record(const RecPool &p, uint64_t pos_i
 template <int CAP> __device__ bool store_record_col(const RecPool &p, uint64_t pos_index, const Col<CAP> &c) {
     const int n = c.n;
     const uint64_t idb = (uint64_t)((n + 1) & ~1) * 4;
-    const uint64_t bytes = 16 + idb + (uint64_t)(3 * n) * 8;
+    const uint64_t bytes = (16 + idb + (uint64_t)(3 * n) * 8 + 15) & ~15ull;
     const uint64_t o = pool_alloc(p, bytes);
     if (o + bytes > p.cap) return false;
     uint8_t *rec = p.base + o;

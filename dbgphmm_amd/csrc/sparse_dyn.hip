@@ -796,7 +796,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
             const size_t o_stop = o_cnt;  // the per-lane count array of the warm-up is free again
             fa.stop = (int *)(wp + o_stop);
             for (int attempt = 0;; attempt++) {
-                fpool.reserve(pool_cap);
+                fpool.reserve(pool_cap + 4096);  // (the backward kernel fetches 1 KB from a record's start whatever its size)
                 fpool_meta.reserve(sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1) * 2);
                 HIP_CHECK(hipMemsetAsync(fpool_meta.p, 0, sizeof(unsigned long long) + sizeof(uint64_t) * (n_pos + 1) * 2, s));
                 fa.pool.base = fpool.as<uint8_t>();

@@ -260,6 +260,89 @@ def diverge(hap: np.ndarray, rate: float, seed: int) -> np.ndarray:
     return np.array(out, dtype=np.uint8)
 
 
+def mutate_exact(seq: np.ndarray, rate: float, rng: np.random.Generator) -> np.ndarray:
+    """random_mutation_with_rng (random_seq.rs:163-181): exactly round(len * rate) edit operations, each at a
+    uniformly drawn index of the ORIGINAL sequence and of a uniformly drawn kind (substitution to a different
+    base / insertion of a random base left of x[i] / deletion of x[i], MutationProfile::uniform), sorted,
+    de-duplicated and applied left to right with a running offset (random_seq.rs:97-120).  Our own PRNG stream:
+    the property, not the reference's data."""
+    seq = np.asarray(seq, dtype=np.uint8)
+    n_mut = max(int(round(seq.shape[0] * rate)), 0)
+    if n_mut == 0 or seq.shape[0] == 0:
+        return seq.copy()
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ops = set()
+    for _ in range(n_mut):
+        ix = int(rng.integers(0, seq.shape[0]))
+        other = [int(b) for b in acgt if int(b) != int(seq[ix])]
+        b_mut = other[int(rng.integers(0, len(other)))]
+        b_ins = int(acgt[int(rng.integers(0, 4))])
+        kind = int(rng.integers(0, 3))
+        # (index, kind order Mut < Ins < Del as in the reference's derive(Ord), base)
+        ops.add((ix, kind, b_mut if kind == 0 else (b_ins if kind == 1 else 0)))
+    out = seq.tolist()
+    offset = 0
+    for ix, kind, b in sorted(ops):
+        j = ix + offset
+        if j < 0 or j >= len(out):
+            continue
+        if kind == 0:
+            out[j] = b
+        elif kind == 1:
+            out.insert(j, b)
+            offset += 1
+        else:
+            del out[j]
+            offset -= 1
+    return np.array(out, dtype=np.uint8)
+
+
+def tandem_repeat_polyploid_with_unique_homo_ends(unit_size: int, n_unit: int, unit_seed: int,
+                                                  divergence_init: float, div_init_seed: int, end_length: int,
+                                                  n_haplotypes: int, divergence_between_haplotypes: float,
+                                                  div_seed: int) -> List[np.ndarray]:
+    """genome.rs:294-340: a random unit repeated n_unit times, mutated once by `divergence_init` (the repeat's own
+    divergence, H0), flanked by a unique prefix / suffix of `end_length` bases that every haplotype shares;
+    haplotype 0 carries the repeat as it is, every further haplotype a copy of it mutated by
+    `divergence_between_haplotypes` (H) -- all drawn from ONE generator seeded by `div_seed`.
+    -> the haplotypes (the reference's `Genome`).  Argument order as in the reference."""
+    unit = random_genome(unit_size, seed=unit_seed * 3 + 17)
+    tandem = np.tile(unit, n_unit)
+    tandem = mutate_exact(tandem, divergence_init, np.random.default_rng([div_init_seed, 0xD1]))
+    prefix = random_genome(end_length, seed=(unit_seed + 1) * 3 + 18)
+    suffix = random_genome(end_length, seed=(unit_seed - 1) * 3 + 1_000_019)
+    haps = [np.concatenate([prefix, tandem, suffix])]
+    rng = np.random.default_rng([div_seed, 0xD2])
+    for _ in range(1, n_haplotypes):
+        haps.append(np.concatenate([prefix, mutate_exact(tandem, divergence_between_haplotypes, rng), suffix]))
+    return haps
+
+
+def genome_phmm(haps: Sequence[np.ndarray], param: PHMMParams) -> PHMMArrays:
+    """The PHMM of the genome itself: GenomeGraph::from_styled_seqs -> to_seq_graph -> to_phmm
+    (genome_graph.rs:252-323, seq_graph.rs:160-211) for linear haplotypes of copy number 1 -- one node per base,
+    chain edges of probability 1, uniform init.  The reference samples its datasets from this model
+    (e2e.rs:163-232: generate_dataset)."""
+    lens = [int(len(h)) for h in haps]
+    n = sum(lens)
+    base = np.concatenate([np.asarray(h, dtype=np.uint8) for h in haps])
+    src = np.arange(n - 1, dtype=np.uint32)
+    ends = np.cumsum(lens)[:-1] - 1  # no edge from the last base of a haplotype to the next haplotype
+    src = np.delete(src, ends) if len(lens) > 1 else src
+    init = np.full(n, -math.log(n))
+    return PHMMArrays(param, base, init, src.astype(np.uint32), (src + 1).astype(np.uint32),
+                      np.zeros(src.shape[0]), np.ones(n, dtype=bool))
+
+
+def sample_genome_reads(haps: Sequence[np.ndarray], param: PHMMParams, coverage: int, read_len: int, seed: int,
+                        max_reads: Optional[int] = None) -> List[bytes]:
+    """generate_dataset (e2e.rs:163-232) on the forward strand: fragments of `read_len` states drawn from the
+    genome's own PHMM at uniformly random start points until genome_size * coverage bases (a fragment that
+    reaches the end of its haplotype stops there)."""
+    gp = genome_phmm(haps, param)
+    return sample_reads(gp, coverage * gp.n_nodes, read_len, seed, max_reads)
+
+
 def _window_hashes(enc: np.ndarray, w: int) -> np.ndarray:
     """polynomial hash (mod 2^64) of every length-w window of enc (uint64 codes)."""
     n = enc.shape[0]

