@@ -19,4 +19,14 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
                  : "memory");
 }
 
+// the same with the address as a wave-uniform base (SGPR pair) plus a 32-bit per-lane byte offset: no 64-bit
+// per-lane address to keep in (or spill from) vector registers
+__device__ __forceinline__ void glds16_sv(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
 }  // namespace phmm

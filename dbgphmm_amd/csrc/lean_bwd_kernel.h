@@ -17,8 +17,8 @@
 //     (a ring of four 1 KB slots; the offsets of 64 positions are fetched by one load);
 //   * the record of the node the column takes in next -- on a unitig the first parent of the one it took in last
 //     (BwdAdj.par0) -- is requested a position ahead, also into LDS;
-//   * the mapping list of a position is assembled in LDS and leaves as ONE 16-byte-per-lane store; its offsets
-//     are written 64 positions at a time; bases come 64 positions per load;
+//   * the mapping list of a position is assembled in LDS and leaves as ONE 16-byte-per-lane store; its offset
+//     is one more store; bases come 64 positions per load;
 //   * every one of these operations is issued from inline asm and counted, every wait is the exact vmcnt(N).
 // Stops, like the generic <64> kernel, at the first position whose nodes do not fit 64 lanes and parks
 // the column in the read's hand-off slot for the 400-slot kernel.
@@ -62,7 +62,7 @@ __device__ __forceinline__ void lb_park(const SparseBwdArgs &a, uint32_t gi, boo
     }
 }
 
-__global__ void __launch_bounds__(64, 3) lean_backward_kernel(const SparseBwdArgs a) {
+__global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArgs a) {
     __shared__ LeanBwdShared sh;
     const int lane = threadIdx.x;
     const uint32_t gi = a.lanes[blockIdx.x];
@@ -92,39 +92,21 @@ __global__ void __launch_bounds__(64, 3) lean_backward_kernel(const SparseBwdArg
     bool stopped = false;
     int stop_at = 0;
 
-    // ---- mapping records: slab of this wave, offsets of the positions done (lane j: position mo_hi - j)
+    // ---- mapping records: slab of this wave
     unsigned long long slab = 0ull, slab_end = 0ull;
-    unsigned long long mofv = 0ull, mofm = 0ull;
-    int mo_hi = 0;
-    auto flush_map_offsets = [&]() {
-        if ((mofm >> lane) & 1ull) vm_store8(&a.mpool.off[q0 + (uint64_t)(mo_hi - lane)], mofv);
-        vm_issued++;
-        mofm = 0ull;
-    };
     // to_mapping_by_score_ratio of the values on the lanes (has: lane carries an entry): kept = val > 0 and within
     // the ratio of the best, sorted descending, equal values by node id
     auto emit = [&](int p, bool has, uint32_t nid, double val) -> bool {
         const double v = has ? val : 0.0;
-        const double p0v = wave_max(v);
+        const double p0v = wave_max_pos(v);
         const bool keep = has && v > 0.0 && v > p0v * a.ratio_lin;
         const unsigned long long km = __ballot(keep);
         const int k = __popcll(km);
-        // ordered by the value the list holds (the log) and equal logs by node id: the same list whatever lanes the
-        // read's nodes sit on and however its reads were grouped (see emit_mapping, mapping_flow.hip)
+        // The list is written in lane order with flag 1 in its header; the builder of the CSR (map_compact) puts it
+        // in the order a list has -- by the value it holds (the log), equal logs by node id, the same list whatever
+        // lanes the read's nodes sit on and however its reads were grouped -- with the whole chip instead of one wave
         const double lv = keep ? log(v) : 0.0;
-        int rank = 0;
-        unsigned long long mm = km;
-        const long long vb = __double_as_longlong(lv);
-        while (mm) {
-            // (l is wave-uniform: scalar lane reads instead of ds_bpermute round trips)
-            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
-            mm &= mm - 1ull;
-            const int ulo = __builtin_amdgcn_readlane((int)(vb & 0xffffffffll), l);
-            const int uhi = __builtin_amdgcn_readlane((int)(vb >> 32), l);
-            const double u = __longlong_as_double(((long long)uhi << 32) | (long long)(unsigned int)ulo);
-            const uint32_t un = (uint32_t)__builtin_amdgcn_readlane((int)nid, l);
-            rank += (u > lv) || (u == lv && un < nid);
-        }
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
         const uint32_t idb = (uint32_t)((k + 1) & ~1) * 4;
         const uint32_t raw = 8 + idb + (uint32_t)k * 8;
         const uint32_t bytes = (raw + 15) & ~15u;
@@ -137,13 +119,11 @@ __global__ void __launch_bounds__(64, 3) lean_backward_kernel(const SparseBwdArg
         }
         if (slab_end > a.mpool.cap) return false;
         uint8_t *rec = a.mpool.base + slab;
-        if (mofm != 0ull && p < mo_hi - 63) flush_map_offsets();
-        if (mofm == 0ull) mo_hi = p;
-        if (lane == mo_hi - p) mofv = slab + 8;
-        mofm |= 1ull << (mo_hi - p);
+        if (lane == 0) vm_store8(&a.mpool.off[q0 + (uint64_t)p], slab + 8);
+        vm_issued++;
         slab += bytes;
         if (lane == 0) {
-            *(unsigned long long *)sh.out = (unsigned long long)(uint32_t)k;
+            *(unsigned long long *)sh.out = (unsigned long long)(uint32_t)k | (1ull << 32);
             if (k & 1) *(uint32_t *)(sh.out + 8 + 4 * k) = 0u;
             if (raw != bytes) *(unsigned long long *)(sh.out + raw) = 0ull;
         }
@@ -177,8 +157,8 @@ __global__ void __launch_bounds__(64, 3) lean_backward_kernel(const SparseBwdArg
         const unsigned long long o1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fofv >> 32), j) << 32) |
                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fofv, j);
         if (o1 != 0ull) {
-            glds16(a.fpool.base + (o1 - 8) + (size_t)lane * 16,
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)sh.ring[p & (LB_RING - 1)]));
+            glds16_sv(a.fpool.base + (o1 - 8), (uint32_t)lane * 16u,
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)sh.ring[p & (LB_RING - 1)]));
             vm_issued++;
         } else if (lane == 0) {
             *(uint32_t *)sh.ring[p & (LB_RING - 1)] = 0xffffffffu;  // no record: reads as "does not fit"
@@ -255,7 +235,7 @@ __global__ void __launch_bounds__(64, 3) lean_backward_kernel(const SparseBwdArg
         if (node != LN_EMPTY) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a record just read out of sh.stage is in registers)
             if (lane < 5)
-                glds16((const uint8_t *)&a.M.badj[node] + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)sh.stage));
+                glds16_sv(&a.M.badj[node], (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)sh.stage));
             vm_issued++;
             rq_adj = vm_issued;
         }
@@ -494,8 +474,9 @@ __global__ void __launch_bounds__(64, 3) lean_backward_kernel(const SparseBwdArg
         double bd = dsum;
         PROFB_T(4)
         // ---- rescale
-        double mx = wave_max(fmax(fmax(bm, bi), bd));
-        const int e = sp_exp_of(mx);
+        int e;
+        if (!wave_exp_of_max_hi(max(max((uint32_t)__double2hiint(bm), (uint32_t)__double2hiint(bi)), (uint32_t)__double2hiint(bd)), e))
+            e = sp_exp_of(wave_max(fmax(fmax(bm, bi), bd)));
         const double sc = sp_pow2(-e);
         bm *= sc;
         bi *= sc;
@@ -533,7 +514,6 @@ __global__ void __launch_bounds__(64, 3) lean_backward_kernel(const SparseBwdArg
                psteps, pt[0] / psteps, pt[1] / psteps, pt[2] / psteps, pt[3] / psteps, pt[4] / psteps, pt[5] / psteps,
                pt[6] / psteps);
 #endif
-    if (mofm != 0ull) flush_map_offsets();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no fetch-ahead may outlive the wave's use of LDS
     // ---- leave: park the column for the next phase, or hand it to the dense backward kernel
     if (stopped && !err) {

@@ -942,9 +942,25 @@ __global__ void __launch_bounds__(BLOCK) map_compact(RecPool mp, uint64_t n_pos,
     const uint32_t *ids = (const uint32_t *)(rec + 8);
     const double *lps = (const double *)(rec + 8 + idb);
     const uint64_t w = pos_off[p];
+    if (((const uint32_t *)rec)[1] == 0u) {
+        for (uint32_t j = 0; j < n; j++) {
+            nodes[w + j] = ids[j];
+            logp[w + j] = lps[j];
+        }
+        return;
+    }
+    // flag 1: a list of the one-lane-per-node backward kernel, still in lane order (lean_bwd_kernel.h).  Its order:
+    // descending by the value it holds, equal values by node id (hint.rs:135-142; ties: DESIGN.md section 2)
     for (uint32_t j = 0; j < n; j++) {
-        nodes[w + j] = ids[j];
-        logp[w + j] = lps[j];
+        const double v = lps[j];
+        const uint32_t id = ids[j];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < n; q++) {
+            const double u = lps[q];
+            rank += (u > v) || (u == v && ids[q] < id);
+        }
+        nodes[w + rank] = id;
+        logp[w + rank] = v;
     }
 }
 __global__ void __launch_bounds__(BLOCK) map_read_max(const uint64_t *read_off, uint64_t R, const uint64_t *pos_off,

@@ -118,6 +118,32 @@ __device__ __forceinline__ double wave_max(double v) {
     v = fmax(v, dpp_d<DPP_ROW_BCAST31, 0xc>(0.0, v));
     return wave_bcast63(v);
 }
+// maximum of unsigned integers over the 64 lanes (one VALU op per step: the DPP move folds into v_max_u32)
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+    v = max(v, (uint32_t)dpp_i<DPP_ROW_SHR1, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<DPP_ROW_SHR2, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<DPP_ROW_SHR4, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<DPP_ROW_SHR8, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<DPP_ROW_BCAST15, 0xa>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<DPP_ROW_BCAST31, 0xc>(0, (int)v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// the same maximum as wave_max (NON-NEGATIVE doubles order like their bit patterns) in two integer passes: the high
+// words, then the low words of the lanes that hold the largest high word -- half the instructions of the f64 form
+__device__ __forceinline__ double wave_max_pos(double v) {
+    const uint32_t hi = (uint32_t)__double2hiint(v), lo = (uint32_t)__double2loint(v);
+    const uint32_t mh = wave_umax(hi);
+    const uint32_t ml = wave_umax(hi == mh ? lo : 0u);
+    return __hiloint2double((int)mh, (int)ml);
+}
+// binary exponent e with max * 2^-e in [0.5, 1) of the largest of NON-NEGATIVE doubles given by their high words
+// (sp_exp_of of the maximum); false when the maximum is zero or denormal (the caller takes the exact route)
+__device__ __forceinline__ bool wave_exp_of_max_hi(uint32_t hi, int &e) {
+    const uint32_t mh = wave_umax(hi);
+    const int be = (int)((mh >> 20) & 0x7ffu);
+    e = be - 1022;
+    return be != 0;
+}
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ int wave_iscan(int v) {
     v += dpp_i<DPP_ROW_SHR1, 0xf>(0, v);
