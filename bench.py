@@ -43,6 +43,12 @@ WORKLOADS = {
     "cfg2": dict(genome=10_000, haplotypes=1, k=40, coverage=20, read_len=1000, p=0.001, mode="dense",
                  desc="cfg2: synthetic 10 kb haploid genome, 20x HiFi reads (p=0.001, L=1000), k=40 DBG, "
                       "dense forward+backward+node posteriors"),
+    # BASELINE.json configs[4]'s graph and read set (the `infer` loop itself is the reference's control plane: per k one
+    # generate_mappings on a new graph, then MAX_ITER candidate batches on its mappings, then the mappings carried to
+    # k+1 -- multi_dbg/posterior.rs:698-826, 314-417, 483-515): --mode mapping / candidates / map_nodes are its steps
+    "cfg5": dict(genome=1_000_000, haplotypes=2, k=40, coverage=20, read_len=1000, p=0.001, mode="sparse",
+                 desc="cfg5: synthetic 1 Mb diploid genome (1% divergence), 20x HiFi reads (p=0.001, L=1000), k=40 DBG "
+                      "(N = 1.3e6); sparse-adaptive forward+backward+posteriors (generate_mappings), chunked"),
     "cfg1m": dict(genome=5_000, haplotypes=2, k=16, coverage=10, read_len=200, p=0.001, mode="sparse",
                   desc="cfg1m: 5 kb diploid, 10x, L=200, k=16, sparse-adaptive flow (small: tests and rehearsals)"),
     "cfg1": dict(genome=1_000, haplotypes=1, k=16, coverage=10, read_len=200, p=0.001, mode="dense",
@@ -268,7 +274,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
-    ap.add_argument("--mode", choices=("mapping", "candidates"), default="mapping")
+    ap.add_argument("--mode", choices=("mapping", "candidates", "map_nodes"), default="mapping")
     ap.add_argument("--candidates", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--read-len", type=int, default=0, help="override the workload's read length (e.g. 10000: HiFi)")
@@ -336,6 +342,40 @@ def main():
         state["ar_ms"] += (time.perf_counter() - t0) * 1e3
 
     cand = None
+    if args.mode == "map_nodes":
+        # Mapping::map_nodes over the read set (hint.rs:60-88) with the node map of hint_kp1_from_hint_k
+        # (multi_dbg.rs:1325-1335): the mappings of the k graph carried to the k+1 graph
+        if world > 1:
+            raise SystemExit("--mode map_nodes is a one-GPU measurement")
+        sg1, map_off, map_nodes, _ = D.kp1_node_map(cfg_haplotypes(args.workload), w["k"])
+        model1 = D.PHMMModel(D.vectorised_to_phmm(sg1, arrays.param.with_(n_warmup=w["k"] + 1), 1))
+        mp0, _ = model.generate_mappings(rc, None, True)
+        for _ in range(max(args.warmup, 1)):
+            mp1 = mp0.map_nodes(model1, map_off, map_nodes)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mp1 = mp0.map_nodes(model1, map_off, map_nodes)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        e0, e1 = int(mp0.arrays()[1].shape[0]), int(mp1.arrays()[1].shape[0])
+        # what the carried lists are for: the hinted likelihood on the k+1 graph (to_full_prob_reads with mappings)
+        tot1, lp1 = model1.to_full_prob_reads(rc, mp1)
+        print(json.dumps({
+            "metric": "read-bases/sec through Mapping::map_nodes (mappings of k carried to k+1)",
+            "value": n_bases * args.steps / dt, "unit": "bases/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": w["desc"] + "; phmm_mappings_map_nodes to the k+1 graph", "n_nodes": N,
+                       "n_nodes_kp1": model1.n_nodes, "reads": len(rc), "bases": n_bases, "entries_k": e0, "entries_kp1": e1,
+                       "map_fan_out_max": int(np.diff(map_off.astype(np.int64)).max()),
+                       "sum_lnP_hinted_kp1": tot1, "finite": bool(np.all(np.isfinite(lp1)))},
+            "roofline": {"bound": "hbm", "achieved": 12.0 * (e0 + e1) * args.steps / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": 12.0 * (e0 + e1) * args.steps / dt / 1e9 / 8000.0, "traffic": None,
+                         "kernel": "map_nodes_kernel", "algorithmic_bytes_per_launch": 12.0 * (e0 + e1),
+                         "note": "12 B per list entry read + 12 B written; one wave per read position (latency-bound merge in LDS)"}}),
+              flush=True)
+        return
     if args.mode == "candidates":
         if w["mode"] != "sparse":
             raise SystemExit("--mode candidates runs on a sparse-flow workload (cfg3, cfg1m)")

@@ -8,7 +8,7 @@ from .params import PHMMParams, MAX_ACTIVE_NODES  # noqa: F401
 from .graph import (PHMMArrays, SeqGraph, mock_linear, mock_crossing, toy_repeat,  # noqa: F401
                     dbg_from_haplotypes, random_genome, diverge, sample_reads, vectorised_to_phmm,
                     mutate_exact, tandem_repeat_polyploid_with_unique_homo_ends, genome_phmm,
-                    sample_genome_reads)
+                    sample_genome_reads, kp1_node_map)
 from .model import PHMMModel, PHMMOutput, ReadCollection, Mappings, DenseTables  # noqa: F401
 from ._ffi import PhmmError, build  # noqa: F401
 

@@ -398,7 +398,12 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     // until the frontier kernels are cheaper the pipeline stays opt-in (PHMM_WORKERS=2..4).
     int n_workers = 1;
     if (const char *e = std::getenv("PHMM_WORKERS")) n_workers = std::max(1, std::min(MAX_WORKERS, std::atoi(e)));
-    int64_t warm_cols = 18;  // dense columns kept per read group by the first plan
+    // Dense columns kept per read group by the first plan.  A read leaves the warm-up when at most warmup_threshold
+    // (200) nodes are inside the ratio: with every base the count falls by ~4, so the switch comes ~log4(N / 200)
+    // columns after the first ~10 (measured means: 15.1 at N = 1.3e5, 17.2 at N = 1.3e6); three more columns leave
+    // ~1 % of the reads to the deferred plan (18 at cfg3; with a fixed 18, cfg5 deferred 10 % of its reads).
+    int64_t warm_cols = 13 + (int64_t)std::ceil(std::log((double)std::max<uint64_t>(m->N, 201) / 200.0) / std::log(4.0));
+    warm_cols = std::max<int64_t>(12, warm_cols);
     if (const char *e = std::getenv("PHMM_WARM_COLS")) warm_cols = std::max(4, std::atoi(e));
     int chunk_groups = 0;  // 0: automatic
     if (const char *e = std::getenv("PHMM_CHUNK_GROUPS")) chunk_groups = std::max(0, std::atoi(e));

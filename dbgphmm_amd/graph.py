@@ -344,27 +344,26 @@ def sample_genome_reads(haps: Sequence[np.ndarray], param: PHMMParams, coverage:
 
 
 def _window_hashes(enc: np.ndarray, w: int) -> np.ndarray:
-    """polynomial hash (mod 2^64) of every length-w window of enc (uint64 codes)."""
+    """polynomial hash (mod 2^64) of every length-w window of enc (uint64 codes):
+    sum_t (enc[i+t]+1) * B^(w-1-t), evaluated blockwise over a sliding-window view."""
     n = enc.shape[0]
-    pw = np.ones(w + 1, dtype=np.uint64)
+    if n < w:
+        return np.zeros(0, dtype=np.uint64)
     with np.errstate(over="ignore"):
-        for j in range(1, w + 1):
+        pw = np.ones(w, dtype=np.uint64)
+        for j in range(1, w):
             pw[j] = pw[j - 1] * _B
-        # prefix hash H[i+1] = H[i]*B + (enc[i]+1) done blockwise via powers
-        # (explicit loop is O(n) python; use cumulative trick with power table instead)
-        # H[i] = sum_{j<i} (enc[j]+1) * B^(i-1-j)  -> window = H[i+w] - H[i]*B^w
-        H = np.zeros(n + 1, dtype=np.uint64)
-        v = enc + np.uint64(1)
-        # iterative doubling is overkill; a simple chunked python loop is fast enough
-        acc = np.uint64(0)
-        Hl = H
-        for i in range(n):
-            acc = acc * _B + v[i]
-            Hl[i + 1] = acc
-        return Hl[w:] - Hl[:-w] * pw[w]
+        coef = pw[::-1].copy()
+        win = np.lib.stride_tricks.sliding_window_view(enc + np.uint64(1), w)
+        out = np.empty(win.shape[0], dtype=np.uint64)
+        step = max(1, (1 << 24) // max(w, 1))
+        for s0 in range(0, win.shape[0], step):
+            blk = win[s0:s0 + step]
+            out[s0:s0 + step] = (blk * coef).sum(axis=1, dtype=np.uint64)
+        return out
 
 
-def dbg_from_haplotypes(haps: Sequence[np.ndarray], k: int) -> SeqGraph:
+def dbg_from_haplotypes(haps: Sequence[np.ndarray], k: int, with_occurrences: bool = False):
     """k-mer graph of the haplotypes with k-1 leading/trailing ``n`` pads
     (kmer/kmer.rs:60-75) as a node-centric SeqGraph: node = distinct k-mer,
     copy number = multiplicity, base = last base, edge u->v iff suffix_{k-1}(u) ==
@@ -419,7 +418,30 @@ def dbg_from_haplotypes(haps: Sequence[np.ndarray], k: int) -> SeqGraph:
     offs = np.concatenate([[0], np.cumsum(cnt)])
     within = np.arange(src.shape[0]) - offs[src]
     dst = porder[lo[src] + within]
-    return SeqGraph(copy_num, base.astype(np.uint8), src.astype(np.uint32), dst.astype(np.uint32), None)
+    sg = SeqGraph(copy_num, base.astype(np.uint8), src.astype(np.uint32), dst.astype(np.uint32), None)
+    if not with_occurrences:
+        return sg
+    # node of every k-mer occurrence, per haplotype (window j of the padded haplotype)
+    cuts = np.cumsum([h.shape[0] for h in km_hash])[:-1]
+    return sg, np.split(node_of_occ, cuts)
+
+
+def kp1_node_map(haps: Sequence[np.ndarray], k: int):
+    """The node map of MultiDbg::hint_kp1_from_hint_k (multi_dbg.rs:1325-1335): a node of the k-HMM (a k-mer) goes to
+    the nodes of the (k+1)-HMM whose (k+1)-mer ends with it (the edges of the k+1 graph into the node that IS the
+    k-mer).  -> (SeqGraph of k+1, map_off[N_k + 1], map_nodes[], SeqGraph of k) for `Mappings.map_nodes`."""
+    sg_k, occ_k = dbg_from_haplotypes(haps, k, True)
+    sg_k1, occ_k1 = dbg_from_haplotypes(haps, k + 1, True)
+    pairs = []
+    for a, b in zip(occ_k, occ_k1):
+        # (k+1)-window j of the haplotype padded with k n's ends with k-window j of the one padded with k-1
+        m = min(a.shape[0], b.shape[0])
+        pairs.append(np.stack([a[:m], b[:m]], axis=1))
+    pr = np.unique(np.concatenate(pairs), axis=0)
+    n_k = sg_k.base.shape[0]
+    cnt = np.bincount(pr[:, 0], minlength=n_k)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+    return sg_k1, off, pr[:, 1].astype(np.uint32), sg_k
 
 
 # ---------------------------------------------------------------- read sampling
