@@ -221,8 +221,8 @@ def pmc_traffic(kernel: str, workload: str):
     (profiles/, made by tools/profile_r2.sh + tools/pmc_traffic.py: FETCH_SIZE / WRITE_SIZE in separate
     passes, corrected with the calibration kernels of tools/pmc_calib.hip).  bench.py cannot collect
     hardware counters itself; None when the summary is absent."""
-    for name in (os.environ.get("PHMM_PMC_SUMMARY"), f"profiles/r2_{workload}_pmc_traffic.json",
-                 f"profiles/r1_{workload}_pmc_traffic.json"):
+    # (only a summary made with THIS round's kernels: an older one would pair other kernels' bytes with these times)
+    for name in (os.environ.get("PHMM_PMC_SUMMARY"), f"profiles/r3_{workload}_pmc_traffic.json"):
         if not name:
             continue
         path = name if os.path.isabs(name) else os.path.join(ROOT, name)
@@ -237,7 +237,20 @@ def pmc_traffic(kernel: str, workload: str):
 
 def spawn_ranks(n: int) -> int:
     """`bench.py --gpus N` from a plain shell: start the N ranks as fresh child processes (this process has not
-    touched a GPU and never will), one per device, rendezvous on 127.0.0.1.  Rank 0 prints the JSON line."""
+    touched a GPU and never will), one per device, rendezvous on 127.0.0.1.  Rank 0 prints the JSON line.
+    The port is picked by binding port 0 and closing the socket: if somebody takes it before rank 0 binds (exit code
+    PORT_TAKEN from init_process_group's short timeout), the launch is repeated once with a fresh port."""
+    for attempt in range(2):
+        rc = _spawn_ranks_once(n)
+        if rc != PORT_TAKEN:
+            return rc
+    return rc
+
+
+PORT_TAKEN = 75
+
+
+def _spawn_ranks_once(n: int) -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -300,10 +313,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", world)):
             backend = "nccl"
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
         else:
-            backend = "gloo"
-            dist.init_process_group("gloo")  # rehearsal only: RCCL refuses two ranks on one device
+            backend = "gloo"  # rehearsal only: RCCL refuses two ranks on one device
+        import datetime
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),  # RCCL over xGMI
+                                        timeout=datetime.timedelta(seconds=120))
+            else:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+        except Exception as e:  # a failed rendezvous ends quickly and visibly (spawn_ranks retries a taken port once)
+            print(f"rank {rank}: rendezvous failed: {e}", file=sys.stderr, flush=True)
+            sys.exit(PORT_TAKEN if "address already in use" in str(e).lower() or "EADDRINUSE" in str(e) else 1)
     dev = torch.device("cuda", local_rank)
 
     import dbgphmm_amd as D
@@ -525,8 +546,10 @@ def main():
                               "sum_lnP_candidate0": float(cand_tot[0]), "per_rank_ms": per_rank_ms,
                               "all_reduce_ms_per_step": state["ar_ms"] / max(args.steps, 1), "backend": backend,
                               "grid": "candidates x read shards (dist.shard_grid)" if world > 1 else "one GPU"},
+                   # (the contract's bounds are "hbm" | "mfma": this kernel is bound by neither -- VALU issue, see the note --
+                   # so the HBM line is filled in with its 4 B / list cell and frac says how little that is)
                    "roofline": {"bound": "hbm", "achieved": 4.0 * cells * args.steps / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                "frac": 4.0 * cells * args.steps / dt / 1e9 / 8000.0, "traffic": None,
+                                "frac": 4.0 * cells * args.steps / dt / 1e9 / 8000.0, "traffic": None, "limiter": "valu-issue",
                                 "kernel": "hinted_lean_kernel", "algorithmic_bytes_per_launch": 4.0 * cells,
                                 "kernel_ms_per_step": ms / max(args.steps, 1), "launches_per_step": n // max(args.steps, 1),
                                 "note": "latency / instruction-issue bound (one wave walks one read for one candidate); "

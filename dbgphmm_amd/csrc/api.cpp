@@ -48,9 +48,40 @@ uint64_t workspace_limit() {
     return (uint64_t)(0.8 * (double)fr);
 }
 
+static Knobs g_knobs;
+const Knobs &knobs() { return g_knobs; }
+void refresh_knobs() {
+    auto flag = [](const char *n) { return std::getenv(n) != nullptr; };
+    auto num = [](const char *n, int dflt) {
+        const char *e = std::getenv(n);
+        return e ? std::atoi(e) : dflt;
+    };
+    Knobs k;
+    k.trace = flag("PHMM_TRACE");
+    k.no_lean = flag("PHMM_NO_LEAN");
+    k.no_packed = flag("PHMM_NO_PACKED");
+    k.packed_cpl = num("PHMM_PACKED_CPL", 0);
+    k.no_exact_hinted = flag("PHMM_NO_EXACT_HINTED");
+    k.no_side_worker = flag("PHMM_NO_SIDE_WORKER");
+    k.no_wide_handover = flag("PHMM_NO_WIDE_HANDOVER");
+    k.workers = std::max(1, std::min(MAX_WORKERS, num("PHMM_WORKERS", 1)));
+    k.warm_cols = num("PHMM_WARM_COLS", 0);
+    k.chunk_groups = std::max(0, num("PHMM_CHUNK_GROUPS", 0));
+    k.pipeline_min_groups = std::max(1, num("PHMM_PIPELINE_MIN_GROUPS", 8));
+    k.no_runmax = flag("PHMM_NO_RUNMAX");
+    k.force_radix = flag("PHMM_FORCE_RADIX");
+    k.serial_emit = flag("PHMM_SERIAL_EMIT");
+    k.no_dma = flag("PHMM_NO_DMA");
+    k.bwd_dma = flag("PHMM_BWD_DMA");
+    k.dense_streams = num("PHMM_DENSE_STREAMS", 0);
+    k.dense_w = num("PHMM_DENSE_W", 0);
+    k.dense_npt = num("PHMM_DENSE_NPT", 0);
+    if (const char *e = std::getenv("PHMM_MEM_FRACTION")) k.mem_fraction = std::min(0.97, std::max(0.1, std::atof(e)));
+    g_knobs = k;
+}
+
 void trace(const char *tag) {
-    static const bool on = std::getenv("PHMM_TRACE") != nullptr;
-    if (!on) return;
+    if (!g_knobs.trace) return;
     static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
     (void)hipStreamSynchronize(g_stream);
     const auto now = std::chrono::steady_clock::now();
@@ -65,8 +96,7 @@ uint64_t table_budget(const DevicePool &pool, uint64_t reserve) {
     if (g_ws_limit) return g_ws_limit;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)16 << 30;
-    double frac = 0.9;
-    if (const char *e = std::getenv("PHMM_MEM_FRACTION")) frac = std::min(0.97, std::max(0.1, std::atof(e)));
+    const double frac = g_knobs.mem_fraction > 0.0 ? g_knobs.mem_fraction : 0.9;
     const double b = frac * (double)(fr + pool.owned_table_bytes()) - (double)reserve;
     return (uint64_t)std::max(b, 64.0 * 1024 * 1024);
 }
@@ -77,8 +107,7 @@ uint64_t planned_budget(const DevicePool &pool) {
     if (g_ws_limit) return g_ws_limit;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)16 << 30;
-    double frac = 0.95;
-    if (const char *e = std::getenv("PHMM_MEM_FRACTION")) frac = std::min(0.97, std::max(0.1, std::atof(e)));
+    const double frac = g_knobs.mem_fraction > 0.0 ? g_knobs.mem_fraction : 0.95;
     return (uint64_t)(frac * (double)(fr + pool.owned_bytes()));
 }
 
@@ -173,6 +202,7 @@ template <class F> static int guarded(F &&f) {
 template <class F> static int guarded_on(phmm_model *m, F &&f) {
     if (!m || !m->pool) return fail(PHMM_EINVAL, "NULL model");
     std::lock_guard<std::recursive_mutex> lk(m->pool->call_mu);
+    refresh_knobs();
     return guarded([&] {
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));

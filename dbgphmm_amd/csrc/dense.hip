@@ -1027,7 +1027,7 @@ struct Timer {
 
 // one forward / backward column for the read groups [g_off, g_off + g_cnt) on stream s (g_cnt < 0: all, current stream)
 template <int W> static void launch_fwd_one(const DenseArgs &a0, int pos, int g_off = 0, int g_cnt = -1, hipStream_t s = nullptr) {
-    static const bool dma = std::getenv("PHMM_NO_DMA") == nullptr;
+    const bool dma = !knobs().no_dma;
     DenseArgs a = a0;
     a.g_off = g_off;
     if (g_cnt < 0) {
@@ -1041,7 +1041,7 @@ template <int W> static void launch_fwd_one(const DenseArgs &a0, int pos, int g_
         hipLaunchKernelGGL((fwd_step<W, false>), dim3(a.nblk8, g_cnt), dim3(BLOCK), 0, s, a, pos);
 }
 template <int W> static void launch_bwd_one(const DenseArgs &a0, int pos, int g_off = 0, int g_cnt = -1, hipStream_t s = nullptr) {
-    static const bool dma = std::getenv("PHMM_BWD_DMA") != nullptr;
+    const bool dma = knobs().bwd_dma;
     DenseArgs a = a0;
     a.g_off = g_off;
     if (g_cnt < 0) {
@@ -1059,7 +1059,7 @@ template <int W> static void launch_bwd_one(const DenseArgs &a0, int pos, int g_
 // the chunk's groups are dealt to up to 4 streams whose launch sequences overlap: while one is in its latency
 // phases another streams.  Large launches (cfg3) fill the chip on their own and stay on one stream.
 static int dense_stream_count(const DenseArgs &a) {
-    static const int forced = std::getenv("PHMM_DENSE_STREAMS") ? std::atoi(std::getenv("PHMM_DENSE_STREAMS")) : 0;
+    const int forced = knobs().dense_streams;
     int k = forced;
     if (k <= 0) {
         const long blocks = (long)a.nblk8 * a.ng;
@@ -1231,8 +1231,8 @@ Plan make_plan_ids(const phmm_model *m, const phmm_reads *reads, const std::vect
     });
     p.W = forced_w > 0 ? forced_w : choose_width(R);
     // (tuning knobs: PHMM_DENSE_W forces the read-group width, PHMM_DENSE_NPT the run length)
-    if (const char *e = std::getenv("PHMM_DENSE_W")) {
-        const int w = std::atoi(e);
+    {
+        const int w = knobs().dense_w;
         if (w == 1 || w == 2 || w == 4 || w == 8 || w == 16 || w == 32 || w == 64) p.W = w;
     }
     p.ng_total = (int)((R + p.W - 1) / p.W);
@@ -1245,7 +1245,7 @@ Plan make_plan_ids(const phmm_model *m, const phmm_reads *reads, const std::vect
     const double lanes_total = (double)m->N * (double)(p.ng_total * p.W);
     while (npt < 64 && lanes_total / (npt * 2) >= 524288.0) npt *= 2;
     while ((int64_t)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows)) > 4096 && npt < 64) npt *= 2;
-    if (const char *e = std::getenv("PHMM_DENSE_NPT")) npt = std::max(2, std::min(256, std::atoi(e) & ~1));
+    if (knobs().dense_npt > 0) npt = std::max(2, std::min(256, knobs().dense_npt & ~1));
     p.npt = npt;
     p.nblk = (int)((m->N + (int64_t)npt * rows - 1) / ((int64_t)npt * rows));
     p.nblk8 = (p.nblk + 7) / 8 * 8;

@@ -296,6 +296,10 @@ struct DenseMapArgs {
     uint32_t *err;
     unsigned long long *eoff;  // [2][lanes] record offsets of the column being emitted (emit_offsets)
     int force_radix;           // tests: take the radix fallback of block_top_from_column
+    // work lists of the column being emitted (emit_offsets): items = which * lanes + lane
+    uint32_t *wl_small;        // lists of 1..64 candidates under the ratio rule: one wave each (emit_dense_small)
+    uint32_t *wl_big;          // the rest: one block each (emit_dense_map)
+    int *wl_count;             // [2]
 };
 
 template <int W>
@@ -492,6 +496,94 @@ __global__ void __launch_bounds__(1024) emit_offsets(const DenseMapArgs ma, cons
         if (it < items) ma.eoff[it] = o;
         o += bytes_of(it);
     }
+    // The work lists of the column: which (lane, which) pairs have a list to write, and by whom.  A list of up to 64
+    // candidates under the ratio rule -- all but the first few columns of a read, 5 entries on average -- is one
+    // wave's work (emit_dense_small); longer ones, fixed-size lists and over-full columns take a block.
+    auto class_of = [&](int it) -> int {  // 0: nothing, 1: small, 2: big
+        if (bytes_of(it) == 0ull) return 0;
+        const int c = (it / lanes == 0 ? ma.cntA : ma.cntB)[it % lanes];
+        return (ma.topk <= 0 && c >= 1 && c <= 64) ? 1 : 2;
+    };
+    __syncthreads();
+    unsigned long long cl = 0ull;  // low word: small items of this thread, high word: big ones
+    for (int q = 0; q < per; q++) {
+        const int c = class_of(tid * per + q);
+        cl += c == 1 ? 1ull : (c == 2 ? (1ull << 32) : 0ull);
+    }
+    part[tid] = cl;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned long long v = tid >= off ? part[tid - off] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long at = part[tid] - cl;
+    for (int q = 0; q < per; q++) {
+        const int it = tid * per + q;
+        const int c = class_of(it);
+        if (c == 1) ma.wl_small[(uint32_t)at] = (uint32_t)it, at += 1ull;
+        else if (c == 2) ma.wl_big[(uint32_t)(at >> 32)] = (uint32_t)it, at += 1ull << 32;
+    }
+    if (tid == 1023) {
+        ma.wl_count[0] = (int)(uint32_t)part[1023];
+        ma.wl_count[1] = (int)(uint32_t)(part[1023] >> 32);
+    }
+}
+
+// A list of up to 64 candidates (node, posterior) of one (lane, which): one wave, one candidate per lane --
+// to_mapping_by_score_ratio (hint.rs:135-142, table.rs:134-149): kept = inside the ratio of the best, ordered by the
+// value the list holds (the log), equal logs by node id (see emit_mapping).  Four independent waves per block.
+__global__ void __launch_bounds__(BLOCK) emit_dense_small(const DenseMapArgs ma, const int pos, const int lanes) {
+    const DenseArgs &a = ma.d;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_items = ma.wl_count[0];
+    for (int w = blockIdx.x * (BLOCK / 64) + wave; w < n_items; w += gridDim.x * (BLOCK / 64)) {
+        const uint32_t it = ma.wl_small[w];
+        const int which = (int)(it / (uint32_t)lanes), gi = (int)(it % (uint32_t)lanes);
+        int *cnt = which == 0 ? ma.cntA : ma.cntB;
+        const int c = cnt[gi];
+        const uint32_t *cn = (which == 0 ? ma.candA_node : ma.candB_node) + (size_t)gi * KMAX;
+        const double *cv = (which == 0 ? ma.candA_val : ma.candB_val) + (size_t)gi * KMAX;
+        const bool has = lane < c;
+        const uint32_t id = has ? cn[lane] : 0u;
+        const double v = has ? cv[lane] : 0.0;
+        const double thr = wave_max(v) * ma.ratio_lin;
+        const bool stay = has && v > 0.0 && v > thr;
+        const double lv = stay ? log(v) : 0.0;
+        const unsigned long long sm = __ballot(stay);
+        const int k = __popcll(sm);
+        int rank = 0;
+        const long long vb = __double_as_longlong(lv);
+        for (unsigned long long mm = sm; mm != 0ull; mm &= mm - 1ull) {
+            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
+            const int ulo = __builtin_amdgcn_readlane((int)(vb & 0xffffffffll), l);
+            const int uhi = __builtin_amdgcn_readlane((int)(vb >> 32), l);
+            const double u = __longlong_as_double(((long long)uhi << 32) | (long long)(unsigned int)ulo);
+            const uint32_t un = (uint32_t)__builtin_amdgcn_readlane((int)id, l);
+            rank += (u > lv) || (u == lv && un < id);
+        }
+        const int mi = which == 0 ? pos : a.len[gi];
+        const uint64_t pidx = ma.lane_pos0[gi] + (uint64_t)(mi - 1);
+        const uint64_t idb = (uint64_t)((k + 1) & ~1) * 4;
+        const uint64_t bytes = 8 + idb + (uint64_t)k * 8;
+        const uint64_t o = ma.eoff[it];
+        if (o + bytes > ma.mpool.cap) {
+            if (lane == 0) atomicOr(&ma.err[gi], SP_ERR_POOL);
+        } else {
+            uint8_t *rec = ma.mpool.base + o;
+            if (lane == 0) {
+                ((uint32_t *)rec)[0] = (uint32_t)k;
+                ((uint32_t *)rec)[1] = 0;
+                ma.mpool.off[pidx] = o + 8;
+            }
+            if (stay) {
+                ((uint32_t *)(rec + 8))[rank] = id;
+                ((double *)(rec + 8 + idb))[rank] = lv;
+            }
+        }
+        if (lane == 0) cnt[gi] = 0;
+    }
 }
 
 // The same selection in three passes over the column instead of ten.  A read whose first bases fit nowhere has
@@ -605,12 +697,14 @@ __device__ int block_top_from_column(const double *col, int stride, int N, doubl
 }
 
 // one wave per (lane, which): sort the collected nodes and write the mapping record
-__global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, const int pos) {
+__global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, const int pos, const int lanes) {
     __shared__ uint32_t ids[KMAX];
     __shared__ double val[KMAX];
     __shared__ uint16_t order[KMAX];
     const DenseArgs &a = ma.d;
-    const int gi = blockIdx.x, which = blockIdx.y;
+    if ((int)blockIdx.x >= ma.wl_count[1]) return;  // (the grid is the host's upper bound of the list)
+    const uint32_t item = ma.wl_big[blockIdx.x];
+    const int gi = (int)(item % (uint32_t)lanes), which = (int)(item / (uint32_t)lanes);
     const int len = a.len[gi];
     if (len == 0) return;
     const int braw = a.bstart[gi];
@@ -659,7 +753,7 @@ __global__ void __launch_bounds__(BLOCK) emit_dense_map(const DenseMapArgs ma, c
     if (threadIdx.x >= 64) return;  // the sort + record write is a single-wave job
     const uint64_t pidx = ma.lane_pos0[gi] + (uint64_t)(mi - 1);
     if (!emit_mapping<KMAX>(ma.mpool, pidx, ids, val, n, ma.ratio_lin, true, order, ma.topk,
-                            (long long)ma.eoff[(size_t)which * gridDim.x + gi])) {
+                            (long long)ma.eoff[item])) {
         if (threadIdx.x == 0) atomicOr(&ma.err[gi], SP_ERR_POOL);
     }
     if (threadIdx.x == 0) cnt[gi] = 0;
@@ -727,7 +821,9 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
                  o_stop = carve(sizeof(int) * lanes),
                  o_bn = carve(sizeof(uint32_t) * (size_t)lanes * KMAX * 2), o_bv = carve(sizeof(double) * (size_t)lanes * KMAX * 2),
                  o_an = carve(sizeof(uint32_t) * (size_t)lanes * KMAX * 2), o_av = carve(sizeof(double) * (size_t)lanes * KMAX * 2),
-                 o_hand = carve(sizeof(BHandoff) * (size_t)lanes), o_eoff = carve(sizeof(unsigned long long) * 2 * (size_t)lanes);
+                 o_hand = carve(sizeof(BHandoff) * (size_t)lanes), o_eoff = carve(sizeof(unsigned long long) * 2 * (size_t)lanes),
+                 o_wls = carve(sizeof(uint32_t) * 2 * (size_t)lanes), o_wlb = carve(sizeof(uint32_t) * 2 * (size_t)lanes),
+                 o_wlc = carve(sizeof(int) * 2);
     ctl.reserve(cb);
     char *cp = (char *)ctl.p;
     // Pa (two buffers, by position parity), the per-run maxima of Pa, and Pb -- the plane of merged index `len`, which
@@ -756,7 +852,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         a.bstart = (const int *)(cp + o_bs);
         a.Pa = pbuf.as<double>();
         a.Pb = need_pb ? pbuf.as<double>() + 2 * (size_t)mc.ngc * NW : pbuf.as<double>();  // (never touched without such a read)
-        a.Prun = std::getenv("PHMM_NO_RUNMAX") ? nullptr : pbuf.as<double>() + (need_pb ? 3 : 2) * (size_t)mc.ngc * NW;
+        a.Prun = knobs().no_runmax ? nullptr : pbuf.as<double>() + (need_pb ? 3 : 2) * (size_t)mc.ngc * NW;
         // backward scratch of the chunk must start clean (a previous attempt may have used it)
         HIP_CHECK(hipMemsetAsync(a.cmaxB, 0, sizeof(unsigned long long) * (size_t)a.ng * a.Lc * W, s));
         HIP_CHECK(hipMemsetAsync(a.pmax, 0, sizeof(unsigned long long) * (size_t)a.ng * (a.Lc + 1) * W, s));
@@ -792,7 +888,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             std::vector<int> hstop(lanes);
             std::vector<uint32_t> herr2(lanes);
             const bool lean_ok =
-                mc.topk == 0 && m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
+                mc.topk == 0 && m->dev.max_degree <= (uint32_t)ADJ_DEG && !knobs().no_lean;
             for (int round = 0; round < 64 && !todo.empty(); round++) {
                 const bool small = (round & 1) == 0;
                 HIP_CHECK(hipMemcpyAsync(cp + o_lanes, todo.data(), sizeof(uint32_t) * todo.size(), hipMemcpyHostToDevice, s));
@@ -852,7 +948,15 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         ma.topk = mc.topk;
         ma.err = (uint32_t *)(cp + o_err);
         ma.eoff = (unsigned long long *)(cp + o_eoff);
-        ma.force_radix = std::getenv("PHMM_FORCE_RADIX") ? 1 : 0;
+        ma.wl_small = (uint32_t *)(cp + o_wls);
+        ma.wl_big = (uint32_t *)(cp + o_wlb);
+        ma.wl_count = (int *)(cp + o_wlc);
+        // lanes still in their dense columns at a position (an upper bound of the lists a column has to write)
+        std::vector<int> live_at((size_t)pos_max + 2, 0);
+        for (int gi = 0; gi < lanes; gi++)
+            if (hb[gi] >= 0) live_at[(size_t)(hb[gi] & ~(1 << 30))]++;
+        for (int p = pos_max - 1; p >= 0; p--) live_at[(size_t)p] += live_at[(size_t)p + 1];
+        ma.force_radix = knobs().force_radix ? 1 : 0;
         const bool st_on = W == 64 && mc.main_plan;  // statistics of the main plan's bwd_step<64> only (bench.py's roofline)
         LaunchTimer lt(timing_enabled() && st_on);
         std::unique_lock<std::mutex> dense_lock;
@@ -870,7 +974,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         for (auto &e : m->pool->cevent[wi])
             if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         // (PHMM_SERIAL_EMIT: the list kernels on the main stream, for profiling them alone)
-        hipStream_t s2 = std::getenv("PHMM_SERIAL_EMIT") ? s : m->pool->cstream[wi];
+        hipStream_t s2 = knobs().serial_emit ? s : m->pool->cstream[wi];
         hipEvent_t *ev_col = &m->pool->cevent[wi][0], *ev_emit = &m->pool->cevent[wi][2];
         bool emitted[2] = {false, false};
         for (int pos = pos_max; pos >= 0; pos--) {
@@ -891,7 +995,12 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             HIP_CHECK(hipEventRecord(ev_col[par], s));
             HIP_CHECK(hipStreamWaitEvent(s2, ev_col[par], 0));
             hipLaunchKernelGGL(emit_offsets, dim3(1), dim3(1024), 0, s2, ma, pos, lanes);
-            hipLaunchKernelGGL(emit_dense_map, dim3(lanes, 2), dim3(BLOCK), 0, s2, ma, pos);
+            {
+                const int ub = std::max(1, live_at[(size_t)pos] * (need_pb ? 2 : 1));
+                hipLaunchKernelGGL(emit_dense_small, dim3((unsigned)std::min(1024, (ub + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
+                                   s2, ma, pos, lanes);
+                hipLaunchKernelGGL(emit_dense_map, dim3((unsigned)ub), dim3(BLOCK), 0, s2, ma, pos, lanes);
+            }
             HIP_CHECK(hipEventRecord(ev_emit[par], s2));
             emitted[par] = true;
             if (st_on) st.launches[1]++;

@@ -328,6 +328,33 @@ struct LaunchTimer {
 // PHMM_TRACE=1: print host-side phase times (syncs the stream; diagnostics only)
 void trace(const char *tag);
 
+// Developer knobs (environment variables; none is needed for normal use).  They are read in ONE place, when a compute
+// entry point takes the device lock (api.cpp: guarded_on), never on the path of a call.
+struct Knobs {
+    bool trace = false;              // PHMM_TRACE: phase timings on stderr
+    bool no_lean = false;            // PHMM_NO_LEAN: generic vector kernels instead of the one-lane-per-node ones
+    bool no_packed = false;          // PHMM_NO_PACKED: one candidate per wave
+    int packed_cpl = 0;              // PHMM_PACKED_CPL: candidates per lane (0: automatic)
+    bool no_exact_hinted = false;    // PHMM_NO_EXACT_HINTED: no wide-range pass over reads that a candidate cuts
+    bool no_side_worker = false;     // PHMM_NO_SIDE_WORKER
+    bool no_wide_handover = false;   // PHMM_NO_WIDE_HANDOVER
+    int workers = 1;                 // PHMM_WORKERS: chunk pipeline
+    int warm_cols = 0;               // PHMM_WARM_COLS: dense columns kept by the main plan (0: from N)
+    int chunk_groups = 0;            // PHMM_CHUNK_GROUPS
+    int pipeline_min_groups = 8;     // PHMM_PIPELINE_MIN_GROUPS
+    bool no_runmax = false;          // PHMM_NO_RUNMAX
+    bool force_radix = false;        // PHMM_FORCE_RADIX
+    bool serial_emit = false;        // PHMM_SERIAL_EMIT
+    bool no_dma = false;             // PHMM_NO_DMA: forward rows through registers
+    bool bwd_dma = false;            // PHMM_BWD_DMA
+    int dense_streams = 0;           // PHMM_DENSE_STREAMS
+    int dense_w = 0;                 // PHMM_DENSE_W
+    int dense_npt = 0;               // PHMM_DENSE_NPT
+    double mem_fraction = 0.0;       // PHMM_MEM_FRACTION (0: the defaults, 0.9 tables / 0.95 planned)
+};
+const Knobs &knobs();
+void refresh_knobs();
+
 void model_build_host(phmm_model *m);    // CSR + logib
 void model_upload(phmm_model *m);        // closures + device arrays
 

@@ -961,8 +961,8 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
     // packed kernels (several candidates per wave) first.
     std::vector<uint32_t> cls[3], pcls[3];
     uint64_t cells = 0;
-    const bool lean_ok = m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
-    const bool packed_ok = n_cand >= 2 && !pool && lean_ok && std::getenv("PHMM_NO_PACKED") == nullptr;
+    const bool lean_ok = m->dev.max_degree <= (uint32_t)ADJ_DEG && !knobs().no_lean;
+    const bool packed_ok = n_cand >= 2 && !pool && lean_ok && !knobs().no_packed;
     for (uint64_t r = 0; r < R; r++) {
         const uint32_t mx = mp->read_max_list[r];
         if (packed_ok && mx <= 32) pcls[mx <= 8 ? 0 : (mx <= 16 ? 1 : 2)].push_back((uint32_t)r);
@@ -996,7 +996,7 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
         HIP_CHECK(hipMemcpyAsync(d_ids.p, pcls[c].data(), pcls[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         const unsigned nr = (unsigned)pcls[c].size();
         // candidates per wave = (64 / WG) x CPL; two per lane once a batch fills such waves
-        const int cpl_env = std::getenv("PHMM_PACKED_CPL") ? std::atoi(std::getenv("PHMM_PACKED_CPL")) : 0;
+        const int cpl_env = knobs().packed_cpl;
         const int G = c == 0 ? 8 : (c == 1 ? 4 : 2);
         const int cpl = cpl_env > 0 ? cpl_env : (n_cand >= (uint32_t)(2 * G) ? 2 : 1);
         const unsigned per_wave = (unsigned)(G * (cpl >= 2 ? 2 : 1));
@@ -1050,7 +1050,7 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
     HIP_CHECK(hipStreamSynchronize(s));
     // (candidate, read) pairs that came back -inf: the reference's InsBegin chain may still carry them (see
     // hinted_exact_kernel) -- recomputed in its own arithmetic
-    if (!pool && std::getenv("PHMM_NO_EXACT_HINTED") == nullptr) {
+    if (!pool && !knobs().no_exact_hinted) {
         std::vector<uint2> pairs;
         for (uint32_t k = 0; k < n_cand; k++)
             for (uint64_t r = 0; r < R; r++)
@@ -1078,6 +1078,17 @@ void full_prob_reads_hinted(phmm_model *m, const phmm_reads *reads, const phmm_m
                 if (hres[q] == hres[q]) h_out[(size_t)pairs[q].x * R + pairs[q].y] = hres[q];
             st.launches[2]++;
         }
+    }
+    if (pool) {
+        // generate_mappings WITH lists (forward + backward over the lists): the backward pass needs the forward columns
+        // of the scaled kernels, which a read that every list node cuts (a k-mer at probability 0 on its path) does not
+        // have.  The reference calls this on to_non_zero_phmm (multi_dbg/posterior.rs:609-618), where no transition
+        // is 0; a model that cuts a read is refused here instead of returning -inf / NaN posteriors.
+        for (uint64_t r = 0; r < R; r++)
+            if (h_out[r] == -INFINITY && reads->off[r + 1] > reads->off[r])
+                PHMM_THROW(PHMM_EINVAL, "generate_mappings with mappings: read " + std::to_string(r) +
+                                            " has probability 0 on its lists under this model (a zero-copy k-mer cuts it); "
+                                            "use the non-zero PHMM (to_non_zero_phmm) for mapping, as the reference does");
     }
     st.ms[2] += tm.stop();
     cells = mp->total_entries;

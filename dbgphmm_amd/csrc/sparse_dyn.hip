@@ -389,24 +389,22 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
     std::thread side_thread;
     bool side_started = false, main_done = false, single_mode = false;
     CallStats side_stats;
-    const bool side_on = std::getenv("PHMM_NO_SIDE_WORKER") == nullptr;
+    const bool side_on = !knobs().no_side_worker;
     std::vector<std::unique_ptr<PlanCtx>> plans;
     int active = 0;
     std::exception_ptr first_error;
     // Default: one worker.  Measured on cfg3 (MI355X): 3 workers cut the step from 514 to 465 ms, but the
     // sparse waves that share the SIMDs with the dense kernels take bwd_step<64> from 4.0 to 2.9 TB/s;
     // until the frontier kernels are cheaper the pipeline stays opt-in (PHMM_WORKERS=2..4).
-    int n_workers = 1;
-    if (const char *e = std::getenv("PHMM_WORKERS")) n_workers = std::max(1, std::min(MAX_WORKERS, std::atoi(e)));
+    int n_workers = knobs().workers;
     // Dense columns kept per read group by the first plan.  A read leaves the warm-up when at most warmup_threshold
     // (200) nodes are inside the ratio: with every base the count falls by ~4, so the switch comes ~log4(N / 200)
     // columns after the first ~10 (measured means: 15.1 at N = 1.3e5, 17.2 at N = 1.3e6); three more columns leave
     // ~1 % of the reads to the deferred plan (18 at cfg3; with a fixed 18, cfg5 deferred 10 % of its reads).
     int64_t warm_cols = 13 + (int64_t)std::ceil(std::log((double)std::max<uint64_t>(m->N, 201) / 200.0) / std::log(4.0));
     warm_cols = std::max<int64_t>(12, warm_cols);
-    if (const char *e = std::getenv("PHMM_WARM_COLS")) warm_cols = std::max(4, std::atoi(e));
-    int chunk_groups = 0;  // 0: automatic
-    if (const char *e = std::getenv("PHMM_CHUNK_GROUPS")) chunk_groups = std::max(0, std::atoi(e));
+    if (knobs().warm_cols > 0) warm_cols = std::max(4, knobs().warm_cols);
+    const int chunk_groups = knobs().chunk_groups;  // 0: automatic
     // Memory plan of the call, fixed HERE (nothing below reads the free-memory counter again).  The budget is a share
     // of free + pool-owned bytes (the pool's buffers are grow-only and reused: all of it is this call's to use).
     // Set aside first: what the buffers that do not scale with the read groups need for this read set -- forward
@@ -564,7 +562,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         // staging on the device: the reads are resident (phmm_reads), the kernels want the bases
         // transposed to [group][pos][W] (dense: the Lc kept columns; sparse: the full length)
         trace("chunk setup");
-        if (std::getenv("PHMM_TRACE"))
+        if (knobs().trace)
             std::fprintf(stderr, "      chunk: groups %d..%d of %d, W %d, kept columns %d, longest read %d\n", g0, g0 + ngc, plan.ng_total, W, Lc, Lfull);
         std::vector<int> hl((size_t)lanes, 0);
         uint64_t dense_cells = 0;
@@ -690,7 +688,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                     const size_t slot = (size_t)g0 * W + gi;
                     deferred->push_back(plan.order[slot]);
                     new_flags[plan.order[slot]] |= PHMM_READ_DEFERRED;
-                    if (std::getenv("PHMM_TRACE"))
+                    if (knobs().trace)
                         std::fprintf(stderr, "      read %u (len %d) still dense at column %d: deferred\n", plan.order[slot],
                                      hl[gi], Lc);
                     hl[gi] = 0;  // not part of this chunk any more
@@ -818,7 +816,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 std::vector<int> hstop(lanes);
                 bool pool_full = false;
                 const bool lean_ok =
-                    by_ratio && m->dev.max_degree <= (uint32_t)ADJ_DEG && std::getenv("PHMM_NO_LEAN") == nullptr;
+                    by_ratio && m->dev.max_degree <= (uint32_t)ADJ_DEG && !knobs().no_lean;
                 for (int round = 0; round < 64 && !todo.empty() && !pool_full; round++) {
                     // round 0: A <400> from the dense column; then B <64> to the end, and for the reads
                     // it could not hold a short C <400> burst followed by B again
@@ -854,7 +852,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                     }
                     todo.swap(next);
                     if (round == 1 && phase == 1 && !pool_full && !todo.empty() && deferred && by_ratio && single_mode && side_on &&
-                        todo.size() <= std::max<size_t>(8, (size_t)lanes / 64) && std::getenv("PHMM_NO_WIDE_HANDOVER") == nullptr) {
+                        todo.size() <= std::max<size_t>(8, (size_t)lanes / 64) && !knobs().no_wide_handover) {
                         // The few reads whose frontier outgrew the one-lane-per-node class (5 of 4 026 on cfg3) would
                         // now take a 400-slot burst and then walk the rest of the read ALONE -- 6 ms of pure latency
                         // on this chunk's critical path, and as much again in the backward pass.  They leave the
@@ -868,11 +866,11 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                                            sparse_lanes.end());
                         HIP_CHECK(hipMemcpyAsync((void *)a.len, hl.data(), hl.size() * sizeof(int), hipMemcpyHostToDevice, s));
                         hand_over(ids);
-                        if (std::getenv("PHMM_TRACE")) std::fprintf(stderr, "      %zu wide reads handed to a plan of their own\n", ids.size());
+                        if (knobs().trace) std::fprintf(stderr, "      %zu wide reads handed to a plan of their own\n", ids.size());
                         todo.clear();
                     }
                     trace(phase == 0 ? "   phase A <400>" : (phase == 1 ? "   phase B <64>" : "   phase C <400>"));
-                    if (std::getenv("PHMM_TRACE")) std::fprintf(stderr, "      remaining lanes %zu\n", todo.size());
+                    if (knobs().trace) std::fprintf(stderr, "      remaining lanes %zu\n", todo.size());
                 }
                 if (!pool_full && !todo.empty()) PHMM_THROW(PHMM_EINTERNAL, "sparse forward did not finish");
                 HIP_CHECK(hipMemcpyAsync(slp.data(), fa.out_logp, sizeof(double) * lanes, hipMemcpyDeviceToHost, s));
@@ -1004,8 +1002,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
         std::unique_ptr<PlanCtx> pc(
             new PlanCtx{make_plan(m, reads, 0), by_ratio ? warm_cols : (int64_t)prm.n_warmup + 2, by_ratio, {}});
         // few groups: one worker (the calling thread, on the caller's stream)
-        int min_groups = 8;
-        if (const char *e = std::getenv("PHMM_PIPELINE_MIN_GROUPS")) min_groups = std::max(1, std::atoi(e));
+        const int min_groups = knobs().pipeline_min_groups;
         if (pc->plan.ng_total < min_groups) n_workers = 1;
         enqueue_plan(std::move(pc), queue);
     }

@@ -68,7 +68,8 @@ int phmm_device_count(void);
 int phmm_set_device(int device);
 /* run subsequent work of this thread on the given hipStream_t (NULL = default stream) */
 int phmm_set_stream(void *hip_stream);
-/* upper bound (bytes) for the DP-table workspace of one call; 0 = 90% of free HBM */
+/* upper bound (bytes) for the workspace of one call; 0 = automatic: the adaptive flow plans 95 % of (free + already
+ * held) HBM for ALL its buffers, the dense drivers take 90 % for their tables */
 int phmm_set_workspace_limit(uint64_t bytes);
 /* Workspaces (DP tables, record pools, scratch) belong to the DEVICE and are shared by every handle on it:
  * a mapping model and a scoring model can be alive together, as in multi_dbg/posterior.rs:247-255, 609-630
@@ -246,7 +247,10 @@ int phmm_mappings_map_nodes(phmm_model *model_after, const phmm_reads *reads,
 
 /* PHMMModel::generate_mappings (hint.rs:193-220): run_with_mapping when `mappings`
  * is given else run_sparse_adaptive(use_max_ratio); then to_mapping_by_score_ratio /
- * to_mapping.  out_node_freq[N] (may be NULL) = Mappings::to_node_freqs. */
+ * to_mapping.  out_node_freq[N] (may be NULL) = Mappings::to_node_freqs.
+ * With `mappings` the model must give every read a positive probability on its lists (the reference maps on
+ * to_non_zero_phmm, multi_dbg/posterior.rs:609-618): a model that cuts a read -- a k-mer at copy number 0 on its
+ * path -- is refused with PHMM_EINVAL; only phmm_full_prob_reads* score such reads (wide-range pass). */
 int phmm_generate_mappings(phmm_model *m, const phmm_reads *reads,
                            const phmm_mappings *mappings, int use_max_ratio,
                            phmm_mappings **out, double *out_node_freq);

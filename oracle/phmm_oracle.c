@@ -224,18 +224,25 @@ static void nv_add_assign(nvec *a, const nvec *b) {
 /* sorted (index,value) pairs, descending by value; ties keep iteration order
  * (assumed stable; unpinned).  Returns up to `k` (<= CAP) entries. */
 typedef struct { uint32_t idx; double val; int ord; } pair_t;
-/* Test hook (tools/fuzz_parity.py): orc_set_tie_rule(e, rev) treats values within e of each other as
- * tied and, with rev, turns the order of tied entries round -- to show that a difference between two
- * restatements is the (unpinned) tie order and nothing else.  Default (0, 0): the rule above. */
+/* Test hook (tools/fuzz_parity.py): orc_set_tie_rule(e, mode) treats values in the same bucket of width e
+ * (floor(val / e), or floor(val / e + 1/2) with mode & 2) as tied and, with mode & 1, turns the order of tied
+ * entries round -- to show that a difference between two restatements is the (unpinned) tie order and nothing
+ * else.  Buckets, not "within e of each other": the comparator stays a strict weak order, as qsort requires.
+ * Default (0, 0): the rule above. */
 static double g_tie_eps = 0.0;
 static int g_tie_rev = 0;
-void orc_set_tie_rule(double eps, int reverse) { g_tie_eps = eps; g_tie_rev = reverse; }
+void orc_set_tie_rule(double eps, int mode) { g_tie_eps = eps; g_tie_rev = mode; }
+static inline double tie_bucket(double v) {
+    if (!(g_tie_eps > 0.0) || !isfinite(v)) return v;
+    return floor(v / g_tie_eps + ((g_tie_rev & 2) ? 0.5 : 0.0));
+}
 static int pair_cmp(const void *a, const void *b) {
     const pair_t *x = a, *y = b;
-    if (x->val > y->val + g_tie_eps) return -1;
-    if (x->val + g_tie_eps < y->val) return 1;
+    const double bx = tie_bucket(x->val), by = tie_bucket(y->val);
+    if (bx > by) return -1;
+    if (bx < by) return 1;
     int o = x->ord < y->ord ? -1 : (x->ord > y->ord ? 1 : 0);
-    return g_tie_rev ? -o : o;
+    return (g_tie_rev & 1) ? -o : o;
 }
 static int nv_sorted_top(const nvec *v, int k, uint32_t *out_idx, double *out_val) {
     int n = nv_count(v);

@@ -116,13 +116,14 @@ def subset_csr(offsets, arrays, idx):
             np.concatenate(logp) if logp else np.zeros(0))
 
 
-TIE_RULES = ((1e-9, 0), (1e-9, 1), (1e-6, 0), (1e-6, 1), (0.0, 1))
+# (bucket width, mode): mode & 1 reverses the order inside a bucket, mode & 2 shifts the buckets by half a width
+TIE_RULES = ((1e-9, 0), (1e-9, 1), (1e-9, 2), (1e-9, 3), (1e-6, 0), (1e-6, 1), (1e-6, 2), (1e-6, 3), (0.0, 1))
 
 
 def compare_mappings_tie_aware(oracle_mod, om, reads, gpu_arrays, orc_arrays, use_max_ratio=True, **kw):
     """compare_mappings read by read; a read that fails is run again through the oracle with its value sorts
-    breaking near-ties the other ways (orc_set_tie_rule: values within 1e-9 / 1e-6 of each other count as tied, in
-    iteration order or reversed) and passes when the GPU lists equal the oracle's under one of them.  The
+    breaking near-ties the other ways (orc_set_tie_rule: values in one bucket of width 1e-9 / 1e-6 count as tied,
+    in iteration order or reversed) and passes when the GPU lists equal the oracle's under one of them.  The
     reference's top-k cuts (table.rs:117-149) sort log values whose last bits are rounding noise, so which of two
     near-equal nodes stays is not a property of the algorithm; what the cut leaves out then moves deep entries
     (below ~1e-8 of the best) by up to a gap probability.  -> (reads that needed another tie order, reads in the overflow regime)."""

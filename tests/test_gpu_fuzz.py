@@ -10,13 +10,27 @@ pytestmark = pytest.mark.gpu
 
 
 def test_random_cases_match_oracle(gpu_lib, oracle):
+    import re
     rng = np.random.default_rng(20261005)
-    seen = {"forced": 0, "tie": 0, "plain": 0}
+    seen = {"cases_with_forced": 0, "plain": 0, "reads": 0, "forced_reads": 0, "tie_reads": 0, "overflow_reads": 0}
     for case in range(40):
         tag = check_case(make_case(rng, case))
-        seen["forced" if "forced=" in tag else "plain"] += 1
-        seen["tie"] += "tie-order" in tag
-    assert seen["plain"] >= 10, seen  # (most cases run the whole comparison)
+        seen["cases_with_forced" if "forced=" in tag else "plain"] += 1
+
+        def num(pat):
+            m = re.search(pat, tag)
+            return int(m.group(1)) if m else 0
+        seen["reads"] += num(r" reads=(\d+)")
+        seen["forced_reads"] += num(r" forced=(\d+)")
+        seen["tie_reads"] += num(r"tie-order reads=(\d+)")
+        seen["overflow_reads"] += num(r"overflow reads=(\d+)")
+    print("\nfuzz:", seen)
+    # The relaxations are bounded.  Forced switches (outside the parity domain, DESIGN.md section 2: weaker checks only)
+    # stay a minority of the cases and of the reads; reads that needed another tie order, or sat in the overflow
+    # regime of the 400-slot vector, stay under 3 % of the reads compared (the sweeps of round 2 saw 11 in 500 cases).
+    assert seen["plain"] >= 20, seen
+    assert seen["forced_reads"] <= 0.25 * seen["reads"], seen
+    assert seen["tie_reads"] + seen["overflow_reads"] <= 0.03 * (seen["reads"] - seen["forced_reads"]), seen
 
 
 def test_random_medium_cases_match_oracle(gpu_lib, oracle):

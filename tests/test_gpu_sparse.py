@@ -159,6 +159,13 @@ def test_reads_cut_by_a_zero_copy_kmer_keep_the_begin_chain(gpu_lib, oracle, mon
     monkeypatch.setenv("PHMM_NO_EXACT_HINTED", "1")
     _, lp4 = gm.to_full_prob_reads_copy_nums(rc, gmp, np.stack([cn1]), 0)
     assert np.all(np.isneginf(lp4[0][cut]))
+    monkeypatch.delenv("PHMM_NO_EXACT_HINTED")
+    # generate_mappings WITH lists needs the forward columns of every read: a model that cuts a read is refused with a
+    # clear error (the reference maps on to_non_zero_phmm, multi_dbg/posterior.rs:609-618), the healthy model is not
+    with pytest.raises(D.PhmmError, match="to_non_zero_phmm"):
+        D.PHMMModel(a1).generate_mappings(rc, gmp, True)
+    mph, _ = gm.generate_mappings(rc, gmp, True)
+    assert np.all(np.isfinite(mph.arrays()[2]))
 
 
 def test_candidate_copy_numbers_on_device(gpu_lib, oracle):
