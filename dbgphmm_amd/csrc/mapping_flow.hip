@@ -966,10 +966,14 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         // columns' bwd_step; the emit-prob plane is double-buffered by position parity for that.
         const int wi = workset_index();
         if (!m->pool->cstream[wi]) {
-            // lowest priority: the list kernels fill the gaps, the HBM-bound bwd_step keeps the machine
+            // The list kernels are small (a few hundred thousand wave-cycles a column) next to the HBM-bound bwd_step
+            // they run beside.  HIGHEST priority: their few blocks are placed as soon as they are ready and are gone
+            // in ~0.1 ms; at the lowest priority they trickled into the gaps bwd_step left and every launch stayed
+            // resident for the whole bwd_step beside it (1.1 ms average, 60 ms of kernel time per cfg3 step for
+            // 0.1 s of single-wave work).  PHMM_EMIT_LOW_PRIORITY=1 restores the old behaviour.
             int least = 0, greatest = 0;
             HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_CHECK(hipStreamCreateWithPriority(&m->pool->cstream[wi], hipStreamNonBlocking, least));
+            HIP_CHECK(hipStreamCreateWithPriority(&m->pool->cstream[wi], hipStreamNonBlocking, knobs().emit_low_priority ? least : greatest));
         }
         for (auto &e : m->pool->cevent[wi])
             if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
