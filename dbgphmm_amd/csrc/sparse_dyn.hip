@@ -817,60 +817,79 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 bool pool_full = false;
                 const bool lean_ok =
                     by_ratio && m->dev.max_degree <= (uint32_t)ADJ_DEG && !knobs().no_lean;
-                for (int round = 0; round < 64 && !todo.empty() && !pool_full; round++) {
-                    // round 0: A <400> from the dense column; then B <64> to the end, and for the reads
-                    // it could not hold a short C <400> burst followed by B again
-                    const int phase = round == 0 ? 0 : ((round & 1) ? 1 : 2);
-                    HIP_CHECK(hipMemcpyAsync(wp + o_lanes, todo.data(), todo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-                    if (phase == 2 && attempt == 0)
-                        for (uint32_t gi : todo) new_flags[plan.order[(size_t)g0 * W + gi]] |= PHMM_READ_WIDE_FRONTIER;
+                // one launch of a phase over `who`: 0 = A <400> from the dense column (6 positions), 1 = B (one lane per
+                // node; `steps` positions at most, 0 = to the end), 2 = C <400> burst of `steps` positions.
+                // -> the lanes that still have positions left; `wide`: those of them that stopped because their frontier
+                // did not fit the class (phase B only)
+                auto run_phase = [&](int phase, int steps, const std::vector<uint32_t> &who, std::vector<uint32_t> &rest,
+                                     std::vector<uint32_t> &wide) {
+                    rest.clear();
+                    wide.clear();
+                    HIP_CHECK(hipMemcpyAsync(wp + o_lanes, who.data(), who.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
                     fa.mode = phase == 0 ? 0 : 1;
-                    // C bursts grow (8, 16, ... 512 positions) so that a read whose frontier stays wide still ends
-                    fa.max_steps = phase == 0 ? 6 : (phase == 2 ? (8 << std::min(round / 2 - 1, 6)) : 0);
+                    fa.max_steps = steps;
                     // B class: one lane per node (lean_fwd_kernel.h); graphs beyond its degree bound use the
                     // generic 128-slot vector kernel
                     if (phase == 1 && lean_ok)
-                        hipLaunchKernelGGL(lean_forward_kernel, dim3((unsigned)todo.size()), dim3(64), 0, s, fa);
+                        hipLaunchKernelGGL(lean_forward_kernel, dim3((unsigned)who.size()), dim3(64), 0, s, fa);
                     else if (phase == 1)
-                        hipLaunchKernelGGL((sparse_forward_kernel<128>), dim3((unsigned)todo.size()), dim3(64), 0, s, fa);
+                        hipLaunchKernelGGL((sparse_forward_kernel<128>), dim3((unsigned)who.size()), dim3(64), 0, s, fa);
                     else
-                        hipLaunchKernelGGL((sparse_forward_kernel<PHMM_MAX_ACTIVE_NODES>), dim3((unsigned)todo.size()), dim3(64),
-                                           0, s, fa);
+                        hipLaunchKernelGGL((sparse_forward_kernel<PHMM_MAX_ACTIVE_NODES>), dim3((unsigned)who.size()), dim3(64), 0, s, fa);
                     HIP_CHECK(hipGetLastError());
                     st.launches[2]++;
                     HIP_CHECK(hipMemcpyAsync(herr.data(), fa.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
                     HIP_CHECK(hipMemcpyAsync(hstop.data(), fa.stop, sizeof(int) * lanes, hipMemcpyDeviceToHost, s));
                     HIP_CHECK(hipStreamSynchronize(s));
-                    std::vector<uint32_t> next;
-                    for (uint32_t gi : todo) {
+                    for (uint32_t gi : who) {
                         if (herr[gi] & SP_ERR_POOL) pool_full = true;
                         else if ((herr[gi] & SP_ERR_CAPACITY) && phase != 1)
                             PHMM_THROW(PHMM_ECAPACITY, "sparse forward: frontier does not fit 400 slots");
                         else if (herr[gi] & ~SP_ERR_CAPACITY)
                             PHMM_THROW(PHMM_EINTERNAL, "sparse forward error " + std::to_string(herr[gi]));
-                        if (hstop[gi] < hl[gi]) next.push_back(gi);
+                        if (hstop[gi] < hl[gi]) ((phase == 1 && (herr[gi] & SP_ERR_CAPACITY)) ? wide : rest).push_back(gi);
                     }
-                    todo.swap(next);
-                    if (round == 1 && phase == 1 && !pool_full && !todo.empty() && deferred && by_ratio && single_mode && side_on &&
-                        todo.size() <= std::max<size_t>(8, (size_t)lanes / 64) && !knobs().no_wide_handover) {
+                    trace(phase == 0 ? "   phase A <400>" : (phase == 1 ? "   phase B <64>" : "   phase C <400>"));
+                    if (knobs().trace) std::fprintf(stderr, "      remaining lanes %zu (+ %zu wide)\n", rest.size(), wide.size());
+                };
+                // A <400> from the dense column; then B to the end of the read.  A read whose frontier outgrows B's
+                // class takes a short C <400> burst and returns to B; C bursts grow (8, 16, ... 512 positions) so that
+                // a frontier that stays wide still ends.  Long reads walk B in slices: a read that goes wide is seen
+                // -- and, on the main plan, handed to a plan of its own on the side stream -- at the end of its slice
+                // and not after every other read of the chunk has walked all of its 10 000 positions.
+                const bool can_hand_over = deferred && by_ratio && single_mode && side_on && !knobs().no_wide_handover;
+                const int b_slice = (can_hand_over && Lfull > 3072) ? 1536 : 0;
+                size_t handed = 0;
+                int bursts = 0;
+                std::vector<uint32_t> rest, wide, tmp1, tmp2;
+                run_phase(0, 6, todo, rest, wide);
+                todo.swap(rest);
+                for (int turn = 0; turn < 100000 && !todo.empty() && !pool_full; turn++) {
+                    run_phase(1, b_slice, todo, rest, wide);
+                    if (pool_full) break;
+                    todo.swap(rest);
+                    if (wide.empty()) continue;
+                    for (uint32_t gi : wide) new_flags[plan.order[(size_t)g0 * W + gi]] |= PHMM_READ_WIDE_FRONTIER;
+                    if (can_hand_over && handed + wide.size() <= std::max<size_t>(8, (size_t)lanes / 64)) {
                         // The few reads whose frontier outgrew the one-lane-per-node class (5 of 4 026 on cfg3) would
-                        // now take a 400-slot burst and then walk the rest of the read ALONE -- 6 ms of pure latency
-                        // on this chunk's critical path, and as much again in the backward pass.  They leave the
-                        // chunk instead and are done from their first base in a plan of their own on the side stream,
-                        // beside this chunk's backward phases (the same route the deferred reads take).
+                        // now take a 400-slot burst and then walk the rest of the read ALONE -- pure latency on this
+                        // chunk's critical path, and as much again in the backward pass.  They leave the chunk instead
+                        // and are done from their first base in a plan of their own on the side stream, beside this
+                        // chunk's remaining phases (the same route the deferred reads take).
                         std::vector<uint32_t> ids;
-                        for (uint32_t gi : todo) ids.push_back(plan.order[(size_t)g0 * W + gi]);
-                        for (uint32_t rd : ids) new_flags[rd] |= PHMM_READ_WIDE_FRONTIER;
-                        for (uint32_t gi : todo) hl[gi] = 0;  // not part of this chunk any more
+                        for (uint32_t gi : wide) ids.push_back(plan.order[(size_t)g0 * W + gi]);
+                        for (uint32_t gi : wide) hl[gi] = 0;  // not part of this chunk any more
                         sparse_lanes.erase(std::remove_if(sparse_lanes.begin(), sparse_lanes.end(), [&](uint32_t gi) { return hl[gi] == 0; }),
                                            sparse_lanes.end());
                         HIP_CHECK(hipMemcpyAsync((void *)a.len, hl.data(), hl.size() * sizeof(int), hipMemcpyHostToDevice, s));
                         hand_over(ids);
+                        handed += ids.size();
                         if (knobs().trace) std::fprintf(stderr, "      %zu wide reads handed to a plan of their own\n", ids.size());
-                        todo.clear();
+                        continue;
                     }
-                    trace(phase == 0 ? "   phase A <400>" : (phase == 1 ? "   phase B <64>" : "   phase C <400>"));
-                    if (knobs().trace) std::fprintf(stderr, "      remaining lanes %zu\n", todo.size());
+                    run_phase(2, 8 << std::min(bursts, 6), wide, tmp1, tmp2);
+                    bursts++;
+                    todo.insert(todo.end(), tmp1.begin(), tmp1.end());
                 }
                 if (!pool_full && !todo.empty()) PHMM_THROW(PHMM_EINTERNAL, "sparse forward did not finish");
                 HIP_CHECK(hipMemcpyAsync(slp.data(), fa.out_logp, sizeof(double) * lanes, hipMemcpyDeviceToHost, s));
