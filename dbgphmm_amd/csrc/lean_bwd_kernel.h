@@ -300,11 +300,19 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
 #else
 #define PROFB_T(k)
 #endif
+    int steps_left = a.max_steps;
+    bool sliced = false;
     for (; !stopped && pos >= s0 + 1 && !err; pos--) {
 #ifdef PHMM_LEAN_PROF
         pc0 = clock64();
         psteps++;
 #endif
+        if (a.max_steps > 0 && steps_left-- == 0) {
+            stopped = true;  // this launch's share of the read is done: the column goes to the hand-off slot
+            sliced = true;
+            stop_at = pos;
+            break;
+        }
         if (xb_hi - pos >= 64) load_bases(pos);
         const uint8_t x = (uint8_t)__builtin_amdgcn_readlane(xb, xb_hi - pos);
         // this position's record is that of pos-1 (requested two positions ago); start the one of pos-3
@@ -542,7 +550,7 @@ __global__ void __launch_bounds__(64, 4) lean_backward_kernel(const SparseBwdArg
         if (lane == 0) a.stop[gi] = s0;
     }
     for (int off = 32; off >= 1; off >>= 1) err |= (uint32_t)__shfl_xor((int)err, off);
-    if (lane == 0) a.err[gi] = err;
+    if (lane == 0) a.err[gi] = err | ((sliced && !err) ? SP_STOP_SLICE : 0u);
 }
 
 }  // namespace phmm

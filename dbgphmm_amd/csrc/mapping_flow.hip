@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
             have_cols = 1;
         }
     }
+    int steps_done = 0;
     for (; !stopped && pos >= s0 + 1 && !err; pos--) {
         // B.tables[pos] over filled_nodes(F.tables[pos-1]) (backward.rs:122-129)
         if (!load_record<CAP>(a.fpool, p0 + (uint64_t)(pos - 1), fr)) {
@@ -229,6 +230,12 @@ __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs
         wave_sync();
         if (!emit_mapping<CAP>(a.mpool, q0 + (uint64_t)(pos - 1), fr.id, val, fr.n, a.ratio_lin, true, order, a.topk))
             err |= SP_ERR_POOL;
+        // a burst (max_steps) ends where the column fits the one-lane-per-node class again
+        if (!a.list_off && a.max_steps > 0 && !err && ++steps_done >= a.max_steps && cur.n <= 64 && pos - 1 >= s0 + 1) {
+            stopped = true;
+            stop_at = pos - 1;
+            break;
+        }
     }
     if (a.list_off) {
         if (stopped) err |= SP_ERR_CAPACITY;  // a forward record is missing or larger than the list class
@@ -882,57 +889,72 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             ba.err = (uint32_t *)(cp + o_err);
             ba.stop = (int *)(cp + o_stop);
             ba.hand = (BHandoff *)(cp + o_hand);
-            // phase 1 <64>: the tail of every read; phase 2 <400>: the positions next to the switch (and
-            // the hand-over to the dense kernel); repeated while a read still has positions left
-            std::vector<uint32_t> todo = sparse_lanes;
+            // <64> kernels (one lane per node): the tail of every read; the 400-slot kernel: the positions next to the
+            // switch (and the hand-over to the dense kernel) and wherever a forward record outgrew the <64> class.
+            // Long reads walk in slices, as in the forward pass (sparse_dyn.hip): the other plans' 400-slot kernels
+            // wait for a running one-wave-per-read kernel of this plan, and a read that met one wide spot returns to
+            // the <64> kernel after a burst instead of crawling to its first base in the 400-slot one.
+            std::vector<uint32_t> todo;
             std::vector<int> hstop(lanes);
             std::vector<uint32_t> herr2(lanes);
             const bool lean_ok =
                 mc.topk == 0 && m->dev.max_degree <= (uint32_t)ADJ_DEG && !knobs().no_lean;
-            for (int round = 0; round < 64 && !todo.empty(); round++) {
-                const bool small = (round & 1) == 0;
-                HIP_CHECK(hipMemcpyAsync(cp + o_lanes, todo.data(), sizeof(uint32_t) * todo.size(), hipMemcpyHostToDevice, s));
-                ba.mode = round == 0 ? 0 : 1;
-                if (small && lean_ok)
-                    hipLaunchKernelGGL(lean_backward_kernel, dim3((unsigned)todo.size()), dim3(64), 0, s, ba);
-                else if (small)
-                    hipLaunchKernelGGL((sparse_backward_kernel<64>), dim3((unsigned)todo.size()), dim3(64), 0, s, ba);
+            const int slice = mc.Lfull > 6144 ? 4096 : 0;  // (a relaunch costs ~0.8 ms: few, long slices)
+            std::vector<uint32_t> cont = sparse_lanes, big, fresh;
+            bool first = true, any_err = false;
+            int bursts = 0;
+            auto launch = [&](int kind, int mode, int steps, const std::vector<uint32_t> &who) {
+                HIP_CHECK(hipMemcpyAsync(cp + o_lanes, who.data(), sizeof(uint32_t) * who.size(), hipMemcpyHostToDevice, s));
+                ba.mode = mode;
+                ba.max_steps = steps;
+                if (kind == 0 && lean_ok)
+                    hipLaunchKernelGGL(lean_backward_kernel, dim3((unsigned)who.size()), dim3(64), 0, s, ba);
+                else if (kind == 0)
+                    hipLaunchKernelGGL((sparse_backward_kernel<64>), dim3((unsigned)who.size()), dim3(64), 0, s, ba);
                 else
-                    hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)todo.size()), dim3(64), 0, s, ba);
+                    hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)who.size()), dim3(64), 0, s, ba);
                 HIP_CHECK(hipGetLastError());
                 st.launches[3]++;
                 HIP_CHECK(hipMemcpyAsync(hstop.data(), ba.stop, sizeof(int) * lanes, hipMemcpyDeviceToHost, s));
                 HIP_CHECK(hipMemcpyAsync(herr2.data(), ba.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                std::vector<uint32_t> next;
-                bool any_err = false;
-                for (uint32_t gi : todo) {
-                    if (herr2[gi]) any_err = true;
-                    else if (hstop[gi] != hsw[gi]) next.push_back(gi);
+            };
+            for (int turn = 0; turn < 100000 && !any_err && (!cont.empty() || !big.empty() || !fresh.empty()); turn++) {
+                std::vector<uint32_t> ncont;
+                if (!cont.empty()) {
+                    launch(0, first ? 0 : 1, lean_ok ? slice : 0, cont);
+                    for (uint32_t gi : cont) {
+                        if (herr2[gi] & ~SP_STOP_SLICE) any_err = true;
+                        else if (hstop[gi] == hsw[gi]) continue;
+                        else if (herr2[gi] & SP_STOP_SLICE) ncont.push_back(gi);
+                        // (a read whose LAST record did not fit <64> has done nothing: it starts in the 400-slot kernel)
+                        else if (first && hstop[gi] == hl[gi]) fresh.push_back(gi);
+                        else big.push_back(gi);
+                    }
+                    first = false;
                 }
                 if (any_err) break;  // reported below (pool growth / internal error)
-                if (round == 0) {
-                    // a read whose LAST record did not fit <64> has done nothing: it restarts in mode 0
-                    bool restart = false;
-                    for (uint32_t gi : next)
-                        if (hstop[gi] == hl[gi]) restart = true;
-                    if (restart) {
-                        std::vector<uint32_t> rs, keep;
-                        for (uint32_t gi : next) (hstop[gi] == hl[gi] ? rs : keep).push_back(gi);
-                        HIP_CHECK(hipMemcpyAsync(cp + o_lanes, rs.data(), sizeof(uint32_t) * rs.size(), hipMemcpyHostToDevice, s));
-                        ba.mode = 0;
-                        hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)rs.size()), dim3(64), 0, s, ba);
-                        HIP_CHECK(hipGetLastError());
-                        HIP_CHECK(hipStreamSynchronize(s));
-                        next.swap(keep);
+                const int burst = slice > 0 ? (64 << std::min(bursts, 5)) : 0;
+                for (int pass = 0; pass < 2 && !any_err; pass++) {
+                    std::vector<uint32_t> &who = pass == 0 ? fresh : big;
+                    if (who.empty()) continue;
+                    launch(1, pass == 0 ? 0 : 1, burst, who);
+                    for (uint32_t gi : who) {
+                        if (herr2[gi] & ~SP_STOP_SLICE) any_err = true;
+                        else if (hstop[gi] != hsw[gi]) ncont.push_back(gi);
                     }
+                    who.clear();
+                    bursts++;
                 }
-                todo.swap(next);
+                cont.swap(ncont);
             }
+            todo = cont;
+            todo.insert(todo.end(), big.begin(), big.end());
+            todo.insert(todo.end(), fresh.begin(), fresh.end());
             if (!todo.empty()) {
                 bool perr = false;
                 HIP_CHECK(hipMemcpy(herr2.data(), ba.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost));
-                for (uint32_t gi : sparse_lanes) perr |= herr2[gi] != 0;
+                for (uint32_t gi : sparse_lanes) perr |= (herr2[gi] & ~SP_STOP_SLICE) != 0;
                 if (!perr) PHMM_THROW(PHMM_EINTERNAL, "sparse backward did not finish");
             }
         }
@@ -1023,7 +1045,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         bool pool_full = false;
         for (int gi = 0; gi < lanes; gi++) {
             if (herr[gi] & SP_ERR_POOL) pool_full = true;
-            else if (herr[gi]) PHMM_THROW(PHMM_EINTERNAL, "mapping backward error " + std::to_string(herr[gi]));
+            else if (herr[gi] & ~SP_STOP_SLICE) PHMM_THROW(PHMM_EINTERNAL, "mapping backward error " + std::to_string(herr[gi]));
         }
         if (!pool_full) break;
         // the pool is shared by every chunk in flight: the whole call restarts with a bigger one

@@ -8,6 +8,7 @@
 
 namespace phmm {
 
+static constexpr uint32_t SP_STOP_SLICE = 64u;  // not an error: the launch's step budget ended (SparseBwdArgs::max_steps)
 static constexpr uint32_t SP_ERR_POOL = 16u;  // record pool exhausted: the host grows it and reruns
 
 // Bump-allocated records in HBM, one per (read, position).
@@ -139,6 +140,8 @@ struct SparseBwdArgs {
     const uint32_t *list_nodes;
     int topk;        // > 0: to_mapping(topk) instead of to_mapping_by_score_ratio
     int mode;        // 0: start at the last position from b_init; 1: resume from the hand-off slot
+    int max_steps;   // > 0: positions to walk at most in this launch (the column is parked in the hand-off slot: <64>
+                     // kernels anywhere -- their err carries SP_STOP_SLICE --, the 400-slot kernel where it fits 64 nodes)
     int *stop;       // [lanes] in (mode 1): position to compute next; out: see below
     BHandoff *hand;  // [lanes]
 };

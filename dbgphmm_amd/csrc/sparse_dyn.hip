@@ -858,7 +858,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 // -- and, on the main plan, handed to a plan of its own on the side stream -- at the end of its slice
                 // and not after every other read of the chunk has walked all of its 10 000 positions.
                 const bool can_hand_over = deferred && by_ratio && single_mode && side_on && !knobs().no_wide_handover;
-                const int b_slice = (can_hand_over && Lfull > 3072) ? 1536 : 0;
+                const int b_slice = (can_hand_over && Lfull > 3072) ? 2048 : 0;
                 size_t handed = 0;
                 int bursts = 0;
                 std::vector<uint32_t> rest, wide, tmp1, tmp2;
