@@ -67,6 +67,7 @@ void refresh_knobs() {
     k.workers = std::max(1, std::min(MAX_WORKERS, num("PHMM_WORKERS", 1)));
     k.warm_cols = num("PHMM_WARM_COLS", 0);
     k.chunk_groups = std::max(0, num("PHMM_CHUNK_GROUPS", 0));
+    k.no_keep_all = flag("PHMM_NO_KEEP_ALL");
     k.pipeline_min_groups = std::max(1, num("PHMM_PIPELINE_MIN_GROUPS", 8));
     k.no_runmax = flag("PHMM_NO_RUNMAX");
     k.force_radix = flag("PHMM_FORCE_RADIX");

@@ -341,6 +341,7 @@ struct Knobs {
     int workers = 1;                 // PHMM_WORKERS: chunk pipeline
     int warm_cols = 0;               // PHMM_WARM_COLS: dense columns kept by the main plan (0: from N)
     int chunk_groups = 0;            // PHMM_CHUNK_GROUPS
+    bool no_keep_all = false;        // PHMM_NO_KEEP_ALL: a small read set defers its slow reads too (see sparse_dyn.hip)
     int pipeline_min_groups = 8;     // PHMM_PIPELINE_MIN_GROUPS
     bool no_runmax = false;          // PHMM_NO_RUNMAX
     bool force_radix = false;        // PHMM_FORCE_RADIX

@@ -480,7 +480,7 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 // (two settings only, all columns or the default: anything in between would follow the small changes of
                 // the budget from call to call and re-allocate a quarter of a terabyte for one column more)
                 const int lc_full = (int)std::min<int64_t>((int64_t)pc->max_len, prm.n_warmup + 2);
-                if ((uint64_t)plan.ng_total * cost(lc_full) <= limit) Lc = lc_full;
+                if ((uint64_t)plan.ng_total * cost(lc_full) <= limit && !knobs().no_keep_all) Lc = lc_full;
                 else
                     for (int cut = 0; cut <= 2 && Lc - cut >= 8; cut++)
                         if ((uint64_t)plan.ng_total * cost(Lc - cut) <= limit) {

@@ -194,6 +194,21 @@ impl<N: PHMMNode, E: PHMMEdge> PHMMModel<N, E> {
         AmdMappings(out).into_mappings(&r)
     }
 
+    /// `generate_mappings` on a read handle the caller keeps (`AmdReads::new(reads)` once per read set).  `infer` passes the
+    /// SAME reads at every k (multi_dbg/posterior.rs:698-826): the handle remembers how many dense warm-up columns
+    /// each read needed in its last adaptive call, the next call groups reads by that (results do not depend on the
+    /// grouping), and only the very first call of a read set runs without hints (bench.py: cold_hint_ms vs ms_per_step).
+    pub fn generate_mappings_amd_on(&self, reads: &AmdReads, mappings: Option<&Mappings>, use_max_ratio: bool) -> Mappings {
+        let m = AmdModel::new(self);
+        let mp = mappings.map(|mp| AmdMappings::from_mappings(reads, mp));
+        let mut out = ptr::null_mut();
+        check(unsafe {
+            phmm_generate_mappings(m.0, reads.h, mp.as_ref().map_or(ptr::null(), |x| x.0 as *const _), use_max_ratio as c_int,
+                                   &mut out, ptr::null_mut())
+        });
+        AmdMappings(out).into_mappings(reads)
+    }
+
     /// drop-in for `to_full_prob_sparse_backward` (freq.rs:153-163; backward_sparse per read, backward.rs:146-185)
     pub fn to_full_prob_sparse_backward_amd<S: Seq>(&self, reads: &ReadCollection<S>) -> Prob {
         let (m, r) = (AmdModel::new(self), AmdReads::new(reads));
