@@ -608,8 +608,8 @@ __device__ int block_top_from_column(const double *col, int stride, int N, doubl
     __shared__ unsigned int hist[TOPH_BINS];
     __shared__ uint32_t bid[TOPH_STAGE];
     __shared__ double bval[TOPH_STAGE];
-    __shared__ int s_bin, s_need, s_n, s_nb, s_wcnt[BLOCK / 64], s_wcnb[BLOCK / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_bin, s_need, s_n, s_nb;
+    const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lo = (unsigned long long)__double_as_longlong(thr > 0.0 ? thr : 0.0);
     const unsigned long long hi = (unsigned long long)__double_as_longlong(vmax);
     const unsigned long long range = hi > lo ? hi - lo : 0ull;
@@ -617,11 +617,22 @@ __device__ int block_top_from_column(const double *col, int stride, int N, doubl
     while ((range >> shift) >= (unsigned long long)TOPH_BINS) shift++;
     for (int h = tid; h < TOPH_BINS; h += BLOCK) hist[h] = 0u;
     __syncthreads();
-    for (int k = tid; k < N; k += BLOCK) {
-        const double v = col[(size_t)k * stride];
-        if (!(v > thr)) continue;
-        const unsigned long long b = ((unsigned long long)__double_as_longlong(v) - lo) >> shift;
-        atomicAdd(&hist[b < (unsigned long long)TOPH_BINS ? (int)b : TOPH_BINS - 1], 1u);
+    // (eight strided loads in flight per thread: a thread that waits for each value of its read's column in turn --
+    // a 64-byte sector per value -- spends the pass waiting)
+    for (int k0 = tid; k0 < N; k0 += 8 * BLOCK) {
+        double v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + u * BLOCK;
+            v8[u] = k < N ? col[(size_t)k * stride] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const double v = v8[u];
+            if (!(v > thr)) continue;
+            const unsigned long long b = ((unsigned long long)__double_as_longlong(v) - lo) >> shift;
+            atomicAdd(&hist[b < (unsigned long long)TOPH_BINS ? (int)b : TOPH_BINS - 1], 1u);
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -637,50 +648,47 @@ __device__ int block_top_from_column(const double *col, int stride, int N, doubl
     }
     __syncthreads();
     const int bstar = s_bin;
-    for (int base = 0; base < N; base += BLOCK) {
-        const int k = base + tid;
-        double v = 0.0;
-        bool take = false, edge = false;
-        if (k < N) {
-            v = col[(size_t)k * stride];
-            if (v > thr) {
+    // (slots are handed out per wave, in no particular order: the list is sorted by (value, node id) afterwards and
+    // everything collected here stays -- no barrier inside the pass over the column)
+    for (int base0 = 0; base0 < N; base0 += 8 * BLOCK) {
+        double v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = base0 + u * BLOCK + tid;
+            v8[u] = k < N ? col[(size_t)k * stride] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = base0 + u * BLOCK + tid;
+            const double v = v8[u];
+            bool take = false, edge = false;
+            if (k < N && v > thr) {
                 unsigned long long b = ((unsigned long long)__double_as_longlong(v) - lo) >> shift;
                 if (b >= (unsigned long long)TOPH_BINS) b = TOPH_BINS - 1;
                 take = (int)b > bstar;
                 edge = (int)b == bstar;
             }
-        }
-        const unsigned long long mk = __ballot(take), me = __ballot(edge);
-        if (lane == 0) {
-            s_wcnt[wave] = __popcll(mk);
-            s_wcnb[wave] = __popcll(me);
-        }
-        __syncthreads();
-        int p = s_n + __popcll(mk & ((1ull << lane) - 1ull)), pb = s_nb + __popcll(me & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; w++) {
-            p += s_wcnt[w];
-            pb += s_wcnb[w];
-        }
-        if (take && p < KMAX) {
-            ids[p] = (uint32_t)k;
-            val[p] = v;
-        }
-        if (edge && pb < TOPH_STAGE) {
-            bid[pb] = (uint32_t)k;
-            bval[pb] = v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int t = s_n, tb = s_nb;
-            for (int w = 0; w < BLOCK / 64; w++) {
-                t += s_wcnt[w];
-                tb += s_wcnb[w];
+            const unsigned long long mk = __ballot(take), me = __ballot(edge);
+            if (mk == 0ull && me == 0ull) continue;
+            int wb = 0, wbb = 0;
+            if (lane == 0) {
+                if (mk) wb = atomicAdd(&s_n, __popcll(mk));
+                if (me) wbb = atomicAdd(&s_nb, __popcll(me));
             }
-            s_n = t;
-            s_nb = tb;
+            wb = __shfl(wb, 0);
+            wbb = __shfl(wbb, 0);
+            const int p = wb + __popcll(mk & ((1ull << lane) - 1ull)), pb = wbb + __popcll(me & ((1ull << lane) - 1ull));
+            if (take && p < KMAX) {
+                ids[p] = (uint32_t)k;
+                val[p] = v;
+            }
+            if (edge && pb < TOPH_STAGE) {
+                bid[pb] = (uint32_t)k;
+                bval[pb] = v;
+            }
         }
-        __syncthreads();
     }
+    __syncthreads();
     const int nabove = s_n, nb = s_nb, need = s_need;
     if (nb > TOPH_STAGE) return block_top_radix(col, stride, N, thr, ids, val);  // (uniform: every thread sees s_nb)
     // the `need` largest of the boundary bin, ties by node id
