@@ -72,7 +72,7 @@ void refresh_knobs() {
     k.no_runmax = flag("PHMM_NO_RUNMAX");
     k.force_radix = flag("PHMM_FORCE_RADIX");
     k.serial_emit = flag("PHMM_SERIAL_EMIT");
-    k.emit_low_priority = flag("PHMM_EMIT_LOW_PRIORITY");
+    k.emit_high_priority = flag("PHMM_EMIT_HIGH_PRIORITY");
     k.no_dma = flag("PHMM_NO_DMA");
     k.bwd_dma = flag("PHMM_BWD_DMA");
     k.dense_streams = num("PHMM_DENSE_STREAMS", 0);

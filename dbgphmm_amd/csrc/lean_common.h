@@ -27,14 +27,19 @@ __device__ __forceinline__ void ln_sync() { wave_sync(); }
 // need.  Operations the compiler issues on rare paths are not counted: N is then smaller than the true distance
 // and the wait is merely conservative.
 __device__ __forceinline__ void vm_wait_upto(int n) {
-    // n: operations issued AFTER the one waited for (wave-uniform)
-    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // n: operations issued AFTER the one waited for (wave-uniform: told to the compiler, or the choice below
+    // becomes nine exec-masked branches)
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n < 4) {
+        if (n < 2) {
+            if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else if (n < 6) {
+        if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }

@@ -136,9 +136,13 @@ template <int CAP>
 __global__ void __launch_bounds__(64) sparse_backward_kernel(const SparseBwdArgs a) {
     __shared__ FRec<CAP> fr;
     __shared__ Col<CAP> cols[2];
-    __shared__ double val[CAP], dA[CAP], dB[CAP];
+    __shared__ double dA[CAP], dB[CAP];
     __shared__ uint32_t list[CAP];
-    __shared__ uint16_t order[CAP];
+    // `val` (node totals before a step, posteriors after it) and `order` (sort scratch, before and after) are never
+    // live while bwd_list_step uses its level buffers dA / dB: they share their memory.  4 KB less: the 400-slot
+    // class at 53.9 KB instead of 57.9, three waves per CU instead of two.
+    double *const val = dA;
+    uint16_t *const order = (uint16_t *)dB;
     const int lane = threadIdx.x;
     const uint32_t gi = a.lanes[blockIdx.x];
     const int g = (int)(gi / a.W), r = (int)(gi % a.W);
@@ -996,14 +1000,14 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
         // columns' bwd_step; the emit-prob plane is double-buffered by position parity for that.
         const int wi = workset_index();
         if (!m->pool->cstream[wi]) {
-            // The list kernels are small (a few hundred thousand wave-cycles a column) next to the HBM-bound bwd_step
-            // they run beside.  HIGHEST priority: their few blocks are placed as soon as they are ready and are gone
-            // in ~0.1 ms; at the lowest priority they trickled into the gaps bwd_step left and every launch stayed
-            // resident for the whole bwd_step beside it (1.1 ms average, 60 ms of kernel time per cfg3 step for
-            // 0.1 s of single-wave work).  PHMM_EMIT_LOW_PRIORITY=1 restores the old behaviour.
+            // Lowest priority: the list kernels fill the gaps the HBM-bound bwd_step leaves.  Their launches then stay
+            // resident for as long as the bwd_step beside them (1.1 ms average: 60 ms of kernel DURATION per cfg3 step
+            // for 0.1 s of single-wave work, SQ_BUSY_CYCLES in profiles/) -- at the highest priority
+            // (PHMM_EMIT_HIGH_PRIORITY=1) they are gone in 0.1-0.5 ms each, 30 ms of duration per step, and bwd_step
+            // pays for it: 5.85 -> 6.3 ms per launch, 221 -> 229 ms per step (measured back to back on one box).
             int least = 0, greatest = 0;
             HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_CHECK(hipStreamCreateWithPriority(&m->pool->cstream[wi], hipStreamNonBlocking, knobs().emit_low_priority ? least : greatest));
+            HIP_CHECK(hipStreamCreateWithPriority(&m->pool->cstream[wi], hipStreamNonBlocking, knobs().emit_high_priority ? greatest : least));
         }
         for (auto &e : m->pool->cevent[wi])
             if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1106,13 +1110,16 @@ __global__ void __launch_bounds__(BLOCK) map_compact(RecPool mp, uint64_t n_pos,
         logp[w + rank] = v;
     }
 }
+// longest list of every read: one wave per read (a thread per read walked 10 000 positions alone: 4.8 ms on 10 kb reads)
 __global__ void __launch_bounds__(BLOCK) map_read_max(const uint64_t *read_off, uint64_t R, const uint64_t *pos_off,
                                                       uint32_t *out) {
-    const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t r = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (r >= R) return;
     uint32_t mx = 0;
-    for (uint64_t p = read_off[r]; p < read_off[r + 1]; p++) mx = max(mx, (uint32_t)(pos_off[p + 1] - pos_off[p]));
-    out[r] = mx;
+    for (uint64_t p = read_off[r] + (uint64_t)lane; p < read_off[r + 1]; p += 64) mx = max(mx, (uint32_t)(pos_off[p + 1] - pos_off[p]));
+    mx = wave_umax(mx);
+    if (lane == 0) out[r] = mx;
 }
 __global__ void __launch_bounds__(BLOCK) map_probs(const double *logp, uint64_t n, double *prob) {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1187,7 +1194,7 @@ static void finish_mappings(phmm_model *m, const phmm_reads *reads, MappingSink 
     DevBuf d_roff, d_rmax;
     d_roff.upload(reads->off.data(), sizeof(uint64_t) * (reads->R + 1));
     d_rmax.reserve(sizeof(uint32_t) * reads->R);
-    hipLaunchKernelGGL(map_read_max, dim3((unsigned)((reads->R + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
+    hipLaunchKernelGGL(map_read_max, dim3((unsigned)((reads->R + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, s,
                        d_roff.as<uint64_t>(), reads->R, mp->d_pos_off.as<uint64_t>(), d_rmax.as<uint32_t>());
     mp->read_max_list.resize(reads->R);
     HIP_CHECK(hipMemcpyAsync(mp->read_max_list.data(), d_rmax.p, sizeof(uint32_t) * reads->R, hipMemcpyDeviceToHost, s));

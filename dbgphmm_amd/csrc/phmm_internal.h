@@ -346,7 +346,7 @@ struct Knobs {
     bool no_runmax = false;          // PHMM_NO_RUNMAX
     bool force_radix = false;        // PHMM_FORCE_RADIX
     bool serial_emit = false;        // PHMM_SERIAL_EMIT
-    bool emit_low_priority = false;  // PHMM_EMIT_LOW_PRIORITY: list kernels of the dense head at the lowest stream priority
+    bool emit_high_priority = false; // PHMM_EMIT_HIGH_PRIORITY: list kernels of the dense head at the highest stream priority
     bool no_dma = false;             // PHMM_NO_DMA: forward rows through registers
     bool bwd_dma = false;            // PHMM_BWD_DMA
     int dense_streams = 0;           // PHMM_DENSE_STREAMS
