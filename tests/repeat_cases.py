@@ -17,6 +17,9 @@ GENOMES = {
     "u100": (100, 10, 0, 0.0, 0, 50, 2, 0.01, 0),       # dbg.rs:77-79 unit 100 bp x 10
     # scripts/sim.sh:187 (run_n4): -U 10000 -N 4 -E 2000 -H 0.01 --H0 0.0002 -P 2 (genome seed 0 -> div_init_seed 1)
     "sim_n4": (10000, 4, 0, 0.0002, 1, 2000, 2, 0.01, 0),
+    # a longer u100: 100 bp unit x 100 (10 kb of repeat) -- long reads whose frontier leaves the 64-lane class again and
+    # again (slices and bursts of both frontier passes)
+    "u100n100": (100, 100, 0, 0.0, 0, 50, 2, 0.01, 0),
     # scripts/sim.sh:218 (run_n10): -U 2000 -N 10 -E 2000
     "sim_n10": (2000, 10, 0, 0.0002, 1, 2000, 2, 0.01, 0),
 }

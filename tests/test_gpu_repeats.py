@@ -157,3 +157,19 @@ def test_sim_shaped_long_reads(gpu_lib, oracle):
     gsub = subset_csr(rc.offsets.astype(np.int64), mp.arrays(), pick)
     ol = oracle.Model(a3).full_prob_reads([reads[r] for r in pick], gsub, True, n_threads=3)
     assert np.max(np.abs(ol - lp[3][pick])) < 1e-6
+
+
+def test_long_reads_on_a_short_unit_repeat(gpu_lib, oracle):
+    """8 kb reads on a 100 bp x 100 tandem repeat (k = 40): nearly every read leaves the one-lane-per-node class many
+    times over its length, too many reads to hand over -- the forward pass walks in slices with 400-slot bursts in
+    between, the backward pass in slices with bursts that return to the one-lane-per-node kernel
+    (sparse_dyn.hip / mapping_flow.hip: run_phase, slices).  Every read against the oracle."""
+    arrays, reads, sg, haps = dataset("u100n100", 40, coverage=5, read_len=8000, p=0.001)
+    assert max(len(r) for r in reads) > 6500 and len(reads) >= 8
+    gm, om, rc, mp, prof = _parity(arrays, reads, oracle)
+    print(f"\nu100n100 L=8000 N={arrays.n_nodes} reads={len(reads)}: {prof}")
+    assert prof["wide_frontier_reads"] >= len(reads) // 2
+    # a second call (grouped by the first call's hints) returns the same bits
+    mp2, _ = gm.generate_mappings(rc, None, True)
+    from helpers import same_mappings
+    assert same_mappings(mp.arrays(), mp2.arrays())
