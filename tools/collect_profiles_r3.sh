@@ -15,6 +15,5 @@ cp $S/rep20_bench.json $P/r3_rep20_bench.json
 cp $S/cfg2_bench.json $P/r3_cfg2_bench.json
 cp $S/cand64_bench.json $P/r3_cand64_bench.json
 cp $S/cand256_bench.json $P/r3_cand256_bench.json
-[ -f gpurun_out/r3_ab_bench.log ] && cp gpurun_out/r3_ab_bench.log $P/r3_ab_same_box_r2_vs_r3.txt
 [ -f gpurun_out/r3_shard8.log ] && grep "shard of\|w0" gpurun_out/r3_shard8.log | tail -20 > $P/r3_shard8_trace.txt
 ls $P | grep r3_
