@@ -114,7 +114,8 @@ __device__ void append_neighbours(const SparseModel &M, bool children, FVec<CAP>
         int deg = 0;
         if (j < nsrc) {
             const uint32_t k = v.id[src_slot[j]];
-            deg = (int)(off[k + 1] - off[k]);
+            if (M.packed) deg = children ? (int)M.fadj[k].nchi : (int)M.fadj[k].npar;
+            else deg = (int)(off[k + 1] - off[k]);
         }
         const int inc = wave_iscan(deg);
         if (j < nsrc) sc.pref[j] = (uint32_t)(running + inc - deg);
@@ -137,7 +138,9 @@ __device__ void append_neighbours(const SparseModel &M, bool children, FVec<CAP>
                 else hi = mid - 1;
             }
             const uint32_t k = v.id[src_slot[lo]];
-            key = nb[off[k] + (uint32_t)(c - (int)sc.pref[lo])];
+            const uint32_t q = (uint32_t)(c - (int)sc.pref[lo]);
+            if (M.packed) key = children ? M.fadj[k].chi[q] : M.fadj[k].par[q];  // (CSR order kept in the records)
+            else key = nb[off[k] + q];
             if (v.n < CAP) {
                 cell = fv_cell(v, key);
             } else {
@@ -249,18 +252,32 @@ __device__ void fwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
     const double c_del = lp.p_ID * ib_cur;
     for (int j = lane; j < na; j += 64) {
         const uint32_t k = cur.id[j];
-        const double pe = M.emis[k] == x ? lp.p_match : lp.p_mismatch;
-        double acc = 0.0;
-        for (uint32_t a = M.par_off[k]; a < M.par_off[k + 1]; a++) {
-            const double w = M.par_w[a];
-            if (w == 0.0) continue;
-            double pm, pi, pd;
-            prev_get(prev, M.par_node[a], pm, pi, pd);
-            acc += w * (lp.p_MM * pm + lp.p_IM * pi + lp.p_DM * pd);
+        double acc = 0.0, pe, ini;
+        if (M.packed) {
+            const FwdAdj r = M.fadj[k];
+            pe = r.emis == x ? lp.p_match : lp.p_mismatch;
+            ini = r.init;
+#pragma unroll
+            for (int q = 0; q < ADJ_DEG; q++) {
+                if (q >= (int)r.npar || r.par_w[q] == 0.0) continue;
+                double pm, pi, pd;
+                prev_get(prev, r.par[q], pm, pi, pd);
+                acc += r.par_w[q] * (lp.p_MM * pm + lp.p_IM * pi + lp.p_DM * pd);
+            }
+        } else {
+            pe = M.emis[k] == x ? lp.p_match : lp.p_mismatch;
+            ini = M.init[k];
+            for (uint32_t a = M.par_off[k]; a < M.par_off[k + 1]; a++) {
+                const double w = M.par_w[a];
+                if (w == 0.0) continue;
+                double pm, pi, pd;
+                prev_get(prev, M.par_node[a], pm, pi, pd);
+                acc += w * (lp.p_MM * pm + lp.p_IM * pi + lp.p_DM * pd);
+            }
         }
         double om, oi, od;
         prev_get(prev, k, om, oi, od);
-        cur.m[j] = pe * (acc + M.init[k] * c_begin);
+        cur.m[j] = pe * (acc + ini * c_begin);
         cur.i[j] = lp.p_random * (lp.p_MI * om + lp.p_II * oi + lp.p_DI * od);
     }
     for (int j = lane; j < CAP; j += 64) {
@@ -288,19 +305,28 @@ __device__ void fwd_adaptive_step(const SparseModel &M, const PrevRef<CAP> &prev
         for (int j = lane; j < nl; j += 64) {
             const int s = lst[j];
             const uint32_t k = cur.id[s];
-            double acc = 0.0;
-            for (uint32_t a = M.par_off[k]; a < M.par_off[k + 1]; a++) {
-                const double w = M.par_w[a];
-                if (w == 0.0) continue;
-                const int ps = fv_find(cur, M.par_node[a]);
-                if (ps < 0) continue;
+            double acc = 0.0, ini = 0.0;
+            auto term = [&](double w, uint32_t parent) {
+                if (w == 0.0) return;
+                const int ps = fv_find(cur, parent);
+                if (ps < 0) return;
                 if (t == 0) {
                     if (ps < na) acc += w * (lp.p_MD * cur.m[ps] + lp.p_ID * cur.i[ps]);  // fd0, forward.rs:480-501
                 } else if (st_prev[ps] == (uint8_t)(t - 1)) {
                     acc += w * lv_prev[ps];  // fdt, forward.rs:510-524
                 }
+            };
+            if (M.packed) {
+                const FwdAdj r = M.fadj[k];
+                ini = r.init;
+#pragma unroll
+                for (int q = 0; q < ADJ_DEG; q++)
+                    if (q < (int)r.npar) term(r.par_w[q], r.par[q]);
+            } else {
+                ini = M.init[k];
+                for (uint32_t a = M.par_off[k]; a < M.par_off[k + 1]; a++) term(M.par_w[a], M.par_node[a]);
             }
-            const double val = t == 0 ? acc + M.init[k] * c_del : lp.p_DD * acc;
+            const double val = t == 0 ? acc + ini * c_del : lp.p_DD * acc;
             lv_cur[s] = val;
             cur.d[s] += val;
         }

@@ -190,6 +190,10 @@ struct SparseModel {
     const ParRec *prec;           // [N] parents + edge ids (hinted forward)
     LinParams lp;
     const double *logib;  // forward InsBegin chain (log), [>= max read length]
+    int packed;           // every node has at most ADJ_DEG parents and children: the packed records are complete, and the
+                          // generic vector kernels read ONE record per node instead of the CSR's offsets -> ids -> weights
+                          // chains (two or three dependent global loads per node and Del level: their whole time on a
+                          // wide frontier)
 };
 
 // Rescale a freshly computed column so that its maximum lies in [0.5, 1).

@@ -102,6 +102,7 @@ inline SparseModel sparse_model_of(const phmm_model *m) {
     s.chi_w = d.chi_w.as<double>();
     s.lp = m->lin;
     s.logib = d.logib.as<double>();
+    s.packed = d.max_degree <= (uint32_t)ADJ_DEG ? 1 : 0;
     return s;
 }
 
