@@ -51,7 +51,10 @@ uint64_t workspace_limit() {
 static Knobs g_knobs;
 const Knobs &knobs() { return g_knobs; }
 void refresh_knobs() {
-    auto flag = [](const char *n) { return std::getenv(n) != nullptr; };
+    auto flag = [](const char *n) {  // set, and not "" / "0"
+        const char *e = std::getenv(n);
+        return e != nullptr && e[0] != '\0' && !(e[0] == '0' && e[1] == '\0');
+    };
     auto num = [](const char *n, int dflt) {
         const char *e = std::getenv(n);
         return e ? std::atoi(e) : dflt;
@@ -59,6 +62,7 @@ void refresh_knobs() {
     Knobs k;
     k.trace = flag("PHMM_TRACE");
     k.no_lean = flag("PHMM_NO_LEAN");
+    k.no_wide_class = flag("PHMM_NO_WIDE_CLASS");
     k.no_packed = flag("PHMM_NO_PACKED");
     k.packed_cpl = num("PHMM_PACKED_CPL", 0);
     k.no_exact_hinted = flag("PHMM_NO_EXACT_HINTED");

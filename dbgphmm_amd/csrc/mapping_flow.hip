@@ -19,6 +19,7 @@
 
 #include "sparse_dyn.h"
 #include "lean_bwd_kernel.h"
+#include "wide_bwd_kernel.h"
 
 namespace phmm {
 
@@ -911,6 +912,7 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
             std::vector<uint32_t> herr2(lanes);
             const bool lean_ok =
                 mc.topk == 0 && m->dev.max_degree <= (uint32_t)ADJ_DEG && !knobs().no_lean;
+            const bool wide_ok = lean_ok && !knobs().no_wide_class;
             const int slice = mc.Lfull > 6144 ? 4096 : 0;  // (a relaunch costs ~0.8 ms: few, long slices)
             std::vector<uint32_t> cont = sparse_lanes, big, fresh;
             bool first = true, any_err = false;
@@ -923,6 +925,8 @@ void mapping_backward_chunk(MapChunk &mc, const std::vector<uint32_t> &sparse_la
                     hipLaunchKernelGGL(lean_backward_kernel, dim3((unsigned)who.size()), dim3(64), 0, s, ba);
                 else if (kind == 0)
                     hipLaunchKernelGGL((sparse_backward_kernel<64>), dim3((unsigned)who.size()), dim3(64), 0, s, ba);
+                else if (wide_ok)  // the 400-slot class on a block of 448 threads (wide_bwd_kernel.h)
+                    hipLaunchKernelGGL(wide_backward_kernel, dim3((unsigned)who.size()), dim3(WBK_T), 0, s, ba);
                 else
                     hipLaunchKernelGGL((sparse_backward_kernel<KMAX>), dim3((unsigned)who.size()), dim3(64), 0, s, ba);
                 HIP_CHECK(hipGetLastError());
@@ -1125,21 +1129,32 @@ __global__ void __launch_bounds__(BLOCK) map_probs(const double *logp, uint64_t 
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j < n) prob[j] = exp(logp[j]);
 }
-// Mappings::to_node_freqs (hint.rs:161-171) in a fixed order: entries are sorted by node (stable
-// radix sort), every node sums its own segment sequentially.
-__global__ void __launch_bounds__(BLOCK) map_node_freq(const uint32_t *sorted_nodes, const double *sorted_prob, uint64_t n,
-                                                       uint32_t N, double *freq) {
-    const uint32_t v = blockIdx.x * BLOCK + threadIdx.x;
-    if (v >= N) return;
+// Mappings::to_node_freqs (hint.rs:161-171) in a fixed order: entries are sorted by node (stable radix sort); ONE WAVE
+// per node sums its segment -- lane l the entries l, l + 64, ... in order, then the lanes in a fixed tree.  The order
+// depends on the segment alone, so the sums are the same whatever the read grouping.  (One thread per node walked
+// its segment alone: 57 000 entries per node on a short-unit tandem repeat, 0.28 s per call on `rep20`.)
+static constexpr int NODE_FREQ_WAVES = 4;
+__global__ void __launch_bounds__(64 * NODE_FREQ_WAVES) map_node_freq(const uint32_t *sorted_nodes, const double *sorted_prob,
+                                                                        uint64_t n, uint32_t N, double *freq) {
+    const uint32_t v = blockIdx.x * NODE_FREQ_WAVES + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (v >= N) return;  // (a whole wave)
     uint64_t lo = 0, hi = n;
     while (lo < hi) {  // first index with node >= v
         const uint64_t mid = (lo + hi) >> 1;
         if (sorted_nodes[mid] < v) lo = mid + 1;
         else hi = mid;
     }
+    uint64_t e0 = lo, e1 = n;
+    while (e0 < e1) {  // first index with node > v
+        const uint64_t mid = (e0 + e1) >> 1;
+        if (sorted_nodes[mid] <= v) e0 = mid + 1;
+        else e1 = mid;
+    }
     double s = 0.0;
-    for (uint64_t j = lo; j < n && sorted_nodes[j] == v; j++) s += sorted_prob[j];
-    freq[v] = s;
+    for (uint64_t j = lo + (uint64_t)lane; j < e0; j += 64) s += sorted_prob[j];
+    s = wave_sum(s);
+    if (lane == 0) freq[v] = s;
 }
 
 static void init_sink(phmm_model *m, const phmm_reads *reads, MappingSink &sink, int topk = 0) {
@@ -1220,7 +1235,7 @@ static void finish_mappings(phmm_model *m, const phmm_reads *reads, MappingSink 
             HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, mp->d_nodes.as<uint32_t>(), d_sn.as<uint32_t>(),
                                                          d_prob.as<double>(), d_sp.as<double>(), (int)total, 0, end_bit, s));
         }
-        hipLaunchKernelGGL(map_node_freq, dim3((m->N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_sn.as<uint32_t>(),
+        hipLaunchKernelGGL(map_node_freq, dim3((m->N + NODE_FREQ_WAVES - 1) / NODE_FREQ_WAVES), dim3(64 * NODE_FREQ_WAVES), 0, s, d_sn.as<uint32_t>(),
                            d_sp.as<double>(), total, m->N, d_freq.as<double>());
         HIP_CHECK(hipGetLastError());
         copy_out(out_node_freq, d_freq.p, sizeof(double) * m->N);

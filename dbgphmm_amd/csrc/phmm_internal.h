@@ -333,6 +333,7 @@ void trace(const char *tag);
 struct Knobs {
     bool trace = false;              // PHMM_TRACE: phase timings on stderr
     bool no_lean = false;            // PHMM_NO_LEAN: generic vector kernels instead of the one-lane-per-node ones
+    bool no_wide_class = false;      // PHMM_NO_WIDE_CLASS: generic 400-slot kernels instead of the one-thread-per-node ones
     bool no_packed = false;          // PHMM_NO_PACKED: one candidate per wave
     int packed_cpl = 0;              // PHMM_PACKED_CPL: candidates per lane (0: automatic)
     bool no_exact_hinted = false;    // PHMM_NO_EXACT_HINTED: no wide-range pass over reads that a candidate cuts

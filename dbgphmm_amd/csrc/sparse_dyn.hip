@@ -28,6 +28,7 @@
 #include "frontier_dev.h"
 #include "sparse_dyn.h"
 #include "sparse_fwd_kernel.h"
+#include "wide_fwd_kernel.h"
 #include "lean_fwd_kernel.h"
 
 namespace phmm {
@@ -821,26 +822,31 @@ void full_prob_reads_sparse(phmm_model *m, const phmm_reads *reads, double *out_
                 // node; `steps` positions at most, 0 = to the end), 2 = C <400> burst of `steps` positions.
                 // -> the lanes that still have positions left; `wide`: those of them that stopped because their frontier
                 // did not fit the class (phase B only)
+                const bool wide_ok = lean_ok && !knobs().no_wide_class;
                 auto run_phase = [&](int phase, int steps, const std::vector<uint32_t> &who, std::vector<uint32_t> &rest,
                                      std::vector<uint32_t> &wide) {
                     rest.clear();
                     wide.clear();
-                    HIP_CHECK(hipMemcpyAsync(wp + o_lanes, who.data(), who.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-                    fa.mode = phase == 0 ? 0 : 1;
-                    fa.max_steps = steps;
-                    // B class: one lane per node (lean_fwd_kernel.h); graphs beyond its degree bound use the
-                    // generic 128-slot vector kernel
-                    if (phase == 1 && lean_ok)
-                        hipLaunchKernelGGL(lean_forward_kernel, dim3((unsigned)who.size()), dim3(64), 0, s, fa);
-                    else if (phase == 1)
-                        hipLaunchKernelGGL((sparse_forward_kernel<128>), dim3((unsigned)who.size()), dim3(64), 0, s, fa);
-                    else
-                        hipLaunchKernelGGL((sparse_forward_kernel<PHMM_MAX_ACTIVE_NODES>), dim3((unsigned)who.size()), dim3(64), 0, s, fa);
-                    HIP_CHECK(hipGetLastError());
-                    st.launches[2]++;
-                    HIP_CHECK(hipMemcpyAsync(herr.data(), fa.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
-                    HIP_CHECK(hipMemcpyAsync(hstop.data(), fa.stop, sizeof(int) * lanes, hipMemcpyDeviceToHost, s));
-                    HIP_CHECK(hipStreamSynchronize(s));
+                    // kind 0: one lane per node (lean_fwd_kernel.h), 1: the 400-slot vectors on a block of 448 threads
+                    // (wide_fwd_kernel.h), 2: the same on one wave (generic), 3: the generic 128-slot one
+                    auto launch = [&](int kind, int mode, const std::vector<uint32_t> &l) {
+                        HIP_CHECK(hipMemcpyAsync(wp + o_lanes, l.data(), l.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                        fa.mode = mode;
+                        fa.max_steps = steps;
+                        const dim3 grid((unsigned)l.size());
+                        if (kind == 0) hipLaunchKernelGGL(lean_forward_kernel, grid, dim3(64), 0, s, fa);
+                        else if (kind == 1) hipLaunchKernelGGL(wide_forward_kernel, grid, dim3(WFK_T), 0, s, fa);
+                        else if (kind == 3) hipLaunchKernelGGL((sparse_forward_kernel<128>), grid, dim3(64), 0, s, fa);
+                        else hipLaunchKernelGGL((sparse_forward_kernel<PHMM_MAX_ACTIVE_NODES>), grid, dim3(64), 0, s, fa);
+                        HIP_CHECK(hipGetLastError());
+                        st.launches[2]++;
+                        HIP_CHECK(hipMemcpyAsync(herr.data(), fa.err, sizeof(uint32_t) * lanes, hipMemcpyDeviceToHost, s));
+                        HIP_CHECK(hipMemcpyAsync(hstop.data(), fa.stop, sizeof(int) * lanes, hipMemcpyDeviceToHost, s));
+                        HIP_CHECK(hipStreamSynchronize(s));
+                    };
+                    // B class: graphs beyond the lean kernel's degree bound use the generic 128-slot vector kernel
+                    if (phase == 1) launch(lean_ok ? 0 : 3, 1, who);
+                    else launch(wide_ok ? 1 : 2, phase == 0 ? 0 : 1, who);  // A / C: the 400-slot class
                     for (uint32_t gi : who) {
                         if (herr[gi] & SP_ERR_POOL) pool_full = true;
                         else if ((herr[gi] & SP_ERR_CAPACITY) && phase != 1)
