@@ -31,11 +31,12 @@ struct WBCol {
 struct WideBwdShared {
     WBCol col[2];
     double fm[WBK_T], fi[WBK_T], fd[WBK_T];  // the forward record
-    uint32_t fid[512];            // (sorted in place with the posteriors by wb_emit)
-    double dA[512], dB[WBK_T];    // level buffers; val = dA, order = dB outside the column step
-    uint32_t list[WBK_T];
-    double red[8];
-    int wsum[8];
+    uint32_t fid[WBK_T];
+    double dA[512], dB[512];      // level buffers; outside the column step: val = dA, order = dB, the list entries being
+                                  // sorted = (dB, list)
+    uint32_t list[512];
+    double red[2][8];
+    int wsum[2][8];
     unsigned long long bc;
 };
 
@@ -61,24 +62,25 @@ __device__ __forceinline__ int wb_find(const WBCol &c, uint32_t id) {
         h = (h + 1) & (WBK_HASH - 1);
     }
 }
-__device__ __forceinline__ double wb_block_max(WideBwdShared &sh, double v) {  // non-negative values
+// (`par` alternates between two sets of wave results: one barrier per reduction)
+__device__ __forceinline__ double wb_block_max(WideBwdShared &sh, int &par, double v) {  // non-negative values
     v = wave_max(v);
-    if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
     __syncthreads();
-    double r = sh.red[0];
+    double r = sh.red[par][0];
 #pragma unroll
-    for (int w = 1; w < WBK_WAVES; w++) r = fmax(r, sh.red[w]);
-    __syncthreads();
+    for (int w = 1; w < WBK_WAVES; w++) r = fmax(r, sh.red[par][w]);
+    par ^= 1;
     return r;
 }
-__device__ __forceinline__ int wb_block_isum(WideBwdShared &sh, int v) {
+__device__ __forceinline__ int wb_block_isum(WideBwdShared &sh, int &par, int v) {
     v = wave_isum(v);
-    if ((threadIdx.x & 63) == 0) sh.wsum[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) sh.wsum[par][threadIdx.x >> 6] = v;
     __syncthreads();
     int r = 0;
 #pragma unroll
-    for (int w = 0; w < WBK_WAVES; w++) r += sh.wsum[w];
-    __syncthreads();
+    for (int w = 0; w < WBK_WAVES; w++) r += sh.wsum[par][w];
+    par ^= 1;
     return r;
 }
 
@@ -107,29 +109,46 @@ __device__ __forceinline__ bool wb_load_record(const RecPool &p, uint64_t pos_in
     return true;
 }
 
-// emit_mapping (mapping_flow.hip) with by_node = true, topk = 0: val[0..n) -> the list record of a position
-__device__ __forceinline__ bool wb_emit(const RecPool &mp, uint64_t pos_index, WideBwdShared &sh, int n, double ratio_lin) {
+__device__ __forceinline__ int wb_excl_scan(WideBwdShared &sh, int &par, int v, int &total) {
+    const int inc = wave_iscan(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) sh.wsum[par][w] = inc;
+    __syncthreads();
+    int pre = 0, tt = 0;
+#pragma unroll
+    for (int k = 0; k < WBK_WAVES; k++) {
+        const int x = sh.wsum[par][k];
+        tt += x;
+        pre += k < w ? x : 0;
+    }
+    total = tt;
+    par ^= 1;
+    return pre + inc - v;
+}
+
+// emit_mapping (mapping_flow.hip) with by_node = true, topk = 0: val[0..n) -> the list record of a position.  Only the
+// entries that stay are sorted (a column next to a wide spot has 400 entries of which a few dozen stay).
+__device__ __forceinline__ bool wb_emit(const RecPool &mp, uint64_t pos_index, WideBwdShared &sh, int &par, int n,
+                                        double ratio_lin) {
     const int t = threadIdx.x;
-    double *val = sh.dA;
-    uint32_t *ids = sh.fid;
-    const double thr = wb_block_max(sh, t < n ? val[t] : 0.0) * ratio_lin;
+    const double v = t < n ? sh.dA[t] : 0.0;
+    double *val = sh.dB;       // the list being built: log values ...
+    uint32_t *ids = sh.list;   // ... and node ids
+    const double thr = wb_block_max(sh, par, v) * ratio_lin;
+    const bool stay = t < n && v > 0.0 && v > thr;
+    int keep;
+    const int at = wb_excl_scan(sh, par, stay ? 1 : 0, keep);
     // the list is ordered by the values it holds -- the LOGS -- and equal logs by node id (emit_mapping)
-    const int NP = bitonic_size(n);
-    int c = 0;
-    for (int k = t; k < NP; k += WBK_T) {
-        bool stay = false;
-        double lv = -INFINITY;
-        if (k < n) {
-            const double v = val[k];
-            stay = v > 0.0 && v > thr;
-            if (stay) lv = log(v);
-        } else {
+    const int NP = bitonic_size(keep);
+    if (stay) {
+        val[at] = log(v);
+        ids[at] = sh.fid[t];
+    }
+    for (int k = t; k < NP; k += WBK_T)
+        if (k >= keep) {
+            val[k] = -INFINITY;
             ids[k] = 0xffffffffu;
         }
-        val[k] = lv;
-        c += stay ? 1 : 0;
-    }
-    const int keep = wb_block_isum(sh, c);
     block_bitonic_desc(val, ids, NP);
     const uint64_t idb = (uint64_t)((keep + 1) & ~1) * 4;
     const uint64_t bytes = 8 + idb + (uint64_t)keep * 8;
@@ -165,6 +184,7 @@ __global__ void __launch_bounds__(WBK_T) wide_backward_kernel(const SparseBwdArg
     const double logP = a.d.logPf[gi];
     const LinParams &lp = a.M.lp;
     uint32_t err = 0;
+    int par = 0;
     const bool ok = logP > -INFINITY;
     int pos;            // next position to compute
     int have_cols = 0;  // col[(pos+1)&1] holds B.tables[pos+1]
@@ -181,7 +201,7 @@ __global__ void __launch_bounds__(WBK_T) wide_backward_kernel(const SparseBwdArg
             const double w = ok ? exp((double)fE * SP_LN2 - logP) * lp.p_end : 0.0;
             if (t < fn) sh.dA[t] = w * (sh.fm[t] + sh.fi[t] + sh.fd[t]);
             __syncthreads();
-            if (!wb_emit(a.mpool, q0 + (uint64_t)(len - 1), sh, fn, a.ratio_lin)) err |= SP_ERR_POOL;
+            if (!wb_emit(a.mpool, q0 + (uint64_t)(len - 1), sh, par, fn, a.ratio_lin)) err |= SP_ERR_POOL;
         }
     } else {
         pos = a.stop[gi];
@@ -308,7 +328,7 @@ __global__ void __launch_bounds__(WBK_T) wide_backward_kernel(const SparseBwdArg
             nd = cur.d[t];
         }
         // rescale (col_rescale): the column maximum into [0.5, 1)
-        const double mx = wb_block_max(sh, fmax(fmax(nm, ni), nd));
+        const double mx = wb_block_max(sh, par, fmax(fmax(nm, ni), nd));
         const int e = sp_exp_of(mx);
         const double sc = sp_pow2(-e);
         const int Ecur = (prev_is_init ? 0 : prev.E) + e;
@@ -327,7 +347,7 @@ __global__ void __launch_bounds__(WBK_T) wide_backward_kernel(const SparseBwdArg
             val[t] = bs >= 0 ? w * (sh.fm[t] * cur.m[bs] + sh.fi[t] * cur.i[bs] + sh.fd[t] * cur.d[bs]) : 0.0;
         }
         __syncthreads();
-        if (!wb_emit(a.mpool, q0 + (uint64_t)(pos - 1), sh, fn, a.ratio_lin)) err |= SP_ERR_POOL;
+        if (!wb_emit(a.mpool, q0 + (uint64_t)(pos - 1), sh, par, fn, a.ratio_lin)) err |= SP_ERR_POOL;
         // a burst (max_steps) ends where the column fits the one-lane-per-node class again
         if (a.max_steps > 0 && !err && ++steps_done >= a.max_steps && nl <= 64 && pos - 1 >= s0 + 1) {
             stopped = true;
@@ -369,7 +389,7 @@ __global__ void __launch_bounds__(WBK_T) wide_backward_kernel(const SparseBwdArg
                 bi[(size_t)c.id[t] * a.W + r] = c.i[t];
                 mx = fmax(c.m[t], c.i[t]);
             }
-            mx = wb_block_max(sh, mx);
+            mx = wb_block_max(sh, par, mx);
             if (t == 0) {
                 a.d.cmaxB[((size_t)g * a.d.Lc + (s0 + 1)) * a.W + r] = (unsigned long long)__double_as_longlong(mx);
                 a.d.BE[((size_t)g * (a.d.Lc + 1) + (s0 + 1)) * a.W + r] = c.E;

@@ -37,15 +37,16 @@ struct WCol {
 };
 struct WideFwdShared {
     WCol col[2];
-    double tot[512];               // element totals (sorted in place) / level values A
-    double lvb[WFK_T];             // level values B
-    uint32_t arb[WFK_HASH];        // per hash cell: first candidate of the batch (also: the first column's candidate ids)
-    uint32_t pref[WFK_T + 1];      // exclusive prefix of the sources' child counts
+    double tot[WFK_T];             // level values A (also: the first column's candidate totals)
+    double lvb[512];               // level values B / the top elements' totals while they are sorted
+    uint32_t arb[WFK_HASH];        // per hash cell: (batch tag | first candidate of that batch); tags count DOWN, so a
+                                   // cell never needs clearing between batches (atomicMin)
+    uint32_t cand[WFK_T];          // the candidate keys of a batch, in candidate order (also: the first column's candidate ids)
     uint32_t chi[ADJ_DEG][WFK_T];  // children of the element in a slot
     uint16_t order[512], la[WFK_T], lb[WFK_T];
     uint8_t sta[WFK_T], stb[WFK_T], nchi[WFK_T];
     int wsum[2][8];
-    double red[8];
+    double red[2][8];
     unsigned long long bc;
 };
 
@@ -105,14 +106,14 @@ __device__ __forceinline__ int wf_excl_scan(WideFwdShared &sh, int &par, int v, 
     par ^= 1;
     return pre + inc - v;
 }
-__device__ __forceinline__ double wf_block_max(WideFwdShared &sh, double v) {  // non-negative values
+__device__ __forceinline__ double wf_block_max(WideFwdShared &sh, int &par, double v) {  // non-negative values
     v = wave_max(v);
-    if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
     __syncthreads();
-    double r = sh.red[0];
+    double r = sh.red[par][0];
 #pragma unroll
-    for (int w = 1; w < WFK_WAVES; w++) r = fmax(r, sh.red[w]);
-    __syncthreads();
+    for (int w = 1; w < WFK_WAVES; w++) r = fmax(r, sh.red[par][w]);
+    par ^= 1;
     return r;
 }
 
@@ -129,29 +130,30 @@ __device__ __forceinline__ void wf_fetch(const SparseModel &M, WideFwdShared &sh
 // append_neighbours (frontier_dev.h) for children: the children of the elements src_slot[0..nsrc) are appended to v in
 // source order without duplicates, up to 400 elements; with a level list, ALL first occurrences at this level are
 // listed in order and stamped.
-__device__ __forceinline__ int wf_append(const SparseModel &M, WideFwdShared &sh, WCol &v, int &par, FwdAdj &rec,
-                                         const uint16_t *src_slot, int nsrc, uint16_t *lvl_list, uint8_t *stamp,
-                                         uint8_t level) {
+__device__ __forceinline__ int wf_append(const SparseModel &M, WideFwdShared &sh, WCol &v, int &par, uint32_t &tag,
+                                         FwdAdj &rec, const uint16_t *src_slot, int nsrc, uint16_t *lvl_list,
+                                         uint8_t *stamp, uint8_t level) {
     const int t = threadIdx.x;
+    // thread t < nsrc speaks for source t: its children are the candidates ex .. ex + deg - 1
     int total;
-    const int deg = t < nsrc ? (int)sh.nchi[src_slot[t]] : 0;
+    const int sslot = t < nsrc ? (int)src_slot[t] : 0;
+    const int deg = t < nsrc ? (int)sh.nchi[sslot] : 0;
     const int ex = wf_excl_scan(sh, par, deg, total);
-    if (t < nsrc) sh.pref[t] = (uint32_t)ex;
-    __syncthreads();
     int nl = 0;      // elements listed at this level so far (uniform)
     int n0 = v.n;    // elements of the vector (uniform; v.n is written back at the end)
     for (int cbase = 0; cbase < total; cbase += WFK_T) {
-        const int c = cbase + t;
-        bool valid = c < total;
+        // the batch's candidate keys, in candidate order
+#pragma unroll
+        for (int q = 0; q < ADJ_DEG; q++) {
+            const int c = ex + q - cbase;
+            if (q < deg && c >= 0 && c < WFK_T) sh.cand[c] = sh.chi[q][sslot];
+        }
+        __syncthreads();
+        bool valid = cbase + t < total;
         uint32_t key = 0, cell = 0;
+        const uint32_t mine = tag | (uint32_t)t;
         if (valid) {
-            int lo = 0, hi = nsrc - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if ((int)sh.pref[mid] <= c) lo = mid;
-                else hi = mid - 1;
-            }
-            key = sh.chi[c - (int)sh.pref[lo]][src_slot[lo]];
+            key = sh.cand[t];
             if (n0 < WFK_CAP) {
                 cell = wf_cell(v, key);
             } else {
@@ -160,12 +162,10 @@ __device__ __forceinline__ int wf_append(const SparseModel &M, WideFwdShared &sh
                 valid = pc >= 0;
                 cell = valid ? (uint32_t)pc : 0u;
             }
-            if (valid) sh.arb[cell] = 0xffffffffu;
+            if (valid) atomicMin(&sh.arb[cell], mine);
         }
         __syncthreads();
-        if (valid) atomicMin(&sh.arb[cell], (uint32_t)t);
-        __syncthreads();
-        const bool winner = valid && sh.arb[cell] == (uint32_t)t;
+        const bool winner = valid && sh.arb[cell] == mine;
         int slot = winner ? (int)v.hslot[cell] : -2;
         const bool is_new = winner && slot == (int)SLOT_NONE;
         const bool old_listed = lvl_list && winner && !is_new && stamp[slot] != level;
@@ -202,6 +202,7 @@ __device__ __forceinline__ int wf_append(const SparseModel &M, WideFwdShared &sh
         // barrier that ends this one)
         if (t >= n0 && t < n1) wf_fetch(M, sh, v, rec);
         n0 = n1;
+        tag -= 512u;
     }
     if (t == 0) v.n = n0;
     __syncthreads();
@@ -219,6 +220,8 @@ __global__ void __launch_bounds__(WFK_T) wide_forward_kernel(const SparseFwdArgs
     const uint64_t p0 = a.lane_pos0[gi];
     const LinParams &lp = a.M.lp;
     int par = 0;
+    uint32_t tag = 0xfffffe00u;  // batch tag of the arbitration cells (wf_append)
+    for (int h = t; h < WFK_HASH; h += WFK_T) sh.arb[h] = 0xffffffffu;
     uint32_t err = 0;
     int pos;        // next position to compute
     int end = len;  // first position this launch does not compute
@@ -240,16 +243,16 @@ __global__ void __launch_bounds__(WFK_T) wide_forward_kernel(const SparseFwdArgs
         const double *ct = a.cand_tot + (size_t)gi * PHMM_MAX_ACTIVE_NODES;
         if (t < nc) {
             sh.tot[t] = ct[t];
-            sh.arb[t] = cn[t];
+            sh.cand[t] = cn[t];
         }
         __syncthreads();
         if (t < nc) {
             const double v = sh.tot[t];
-            const uint32_t id = sh.arb[t];
+            const uint32_t id = sh.cand[t];
             int rank = 0;
             for (int q = 0; q < nc; q++) {
                 const double u = sh.tot[q];
-                rank += (u > v) || (u == v && sh.arb[q] < id);
+                rank += (u > v) || (u == v && sh.cand[q] < id);
             }
             c0.id[rank] = id;
             c0.m[rank] = c0.i[rank] = c0.d[rank] = 0.0;
@@ -310,19 +313,25 @@ __global__ void __launch_bounds__(WFK_T) wide_forward_kernel(const SparseFwdArgs
             // ---- top_nodes_by_score_ratio of the previous column (table.rs:134-149) as the first elements of cur
             const int n = prev.n;
             wf_clear(cur);
-            // stable descending sort of the totals (sort_desc, frontier_dev.h): (total, slot) pairs, in place
-            const int NP = bitonic_size(n);
-            for (int k = t; k < NP; k += WFK_T) {
-                sh.tot[k] = k < n ? prev.m[k] + prev.i[k] + prev.d[k] : -1.0;
-                sh.order[k] = (uint16_t)k;
+            // The elements inside the ratio are the largest ones: their rank in the stable descending sort of all
+            // totals (sort_desc, frontier_dev.h) is their rank among themselves -- only they are sorted, as
+            // (total, slot) pairs
+            const double mytot = t < n ? prev.m[t] + prev.i[t] + prev.d[t] : 0.0;
+            const double t0 = wf_block_max(sh, par, mytot);
+            const int mine = (t < n && mytot > 0.0 && mytot > t0 * a.ratio_lin) ? 1 : 0;
+            int ntop;
+            const int at = wf_excl_scan(sh, par, mine, ntop);
+            const int NP = bitonic_size(ntop);
+            if (mine) {
+                sh.lvb[at] = mytot;
+                sh.order[at] = (uint16_t)t;
             }
-            block_bitonic_desc(sh.tot, sh.order, NP);
-            int ntop = 0;
-            if (n > 0) {
-                const double t0 = sh.tot[0];
-                const int mine = (t < n && sh.tot[t] > 0.0 && sh.tot[t] > t0 * a.ratio_lin) ? 1 : 0;
-                wf_excl_scan(sh, par, mine, ntop);
-            }
+            for (int k = t; k < NP; k += WFK_T)
+                if (k >= ntop) {
+                    sh.lvb[k] = -1.0;
+                    sh.order[k] = (uint16_t)k;
+                }
+            block_bitonic_desc(sh.lvb, sh.order, NP);
             if (t < ntop) {
                 const uint32_t id = prev.id[sh.order[t]];
                 cur.id[t] = id;
@@ -340,7 +349,7 @@ __global__ void __launch_bounds__(WFK_T) wide_forward_kernel(const SparseFwdArgs
         const int Eprev = dense_prev ? E_dense : prev.E;
         if (t < ntop) sh.order[t] = (uint16_t)t;
         __syncthreads();
-        wf_append(a.M, sh, cur, par, rec, sh.order, ntop, nullptr, nullptr, 0);
+        wf_append(a.M, sh, cur, par, tag, rec, sh.order, ntop, nullptr, nullptr, 0);
         const int na = cur.n;
         if (t == 0) cur.na = na;
         // fm (forward.rs:337-359), fi (378-388), fib (541-545)
@@ -386,13 +395,16 @@ __global__ void __launch_bounds__(WFK_T) wide_forward_kernel(const SparseFwdArgs
         // adaptive fd (forward.rs:423-466): S0 = to_childs(active), S_t = to_childs(S_{t-1})
         const uint16_t *src = sh.order;
         int nsrc = na;
+        int pslot[ADJ_DEG];  // slots of this element's parents in the column, once found (elements never move)
+#pragma unroll
+        for (int q = 0; q < ADJ_DEG; q++) pslot[q] = -1;
         for (int lvl = 0; lvl <= lp.n_max_gaps; lvl++) {
             uint16_t *lst = (lvl & 1) ? sh.lb : sh.la;
             uint8_t *st_cur = (lvl & 1) ? sh.stb : sh.sta;
             const uint8_t *st_prev = (lvl & 1) ? sh.sta : sh.stb;
             double *lv_cur = (lvl & 1) ? sh.lvb : sh.tot;
             const double *lv_prev = (lvl & 1) ? sh.tot : sh.lvb;
-            const int nl = wf_append(a.M, sh, cur, par, rec, src, nsrc, lst, st_cur, (uint8_t)lvl);
+            const int nl = wf_append(a.M, sh, cur, par, tag, rec, src, nsrc, lst, st_cur, (uint8_t)lvl);
             // the elements listed at this level are the slots stamped with it: each by its own thread
             if (t < cur.n && st_cur[t] == (uint8_t)lvl) {
                 double acc = 0.0;
@@ -401,7 +413,8 @@ __global__ void __launch_bounds__(WFK_T) wide_forward_kernel(const SparseFwdArgs
                     if (q >= (int)rec.npar) continue;
                     const double w = rec.par_w[q];
                     if (w == 0.0) continue;
-                    const int ps = wf_find(cur, rec.par[q]);
+                    if (pslot[q] < 0) pslot[q] = wf_find(cur, rec.par[q]);
+                    const int ps = pslot[q];
                     if (ps < 0) continue;
                     if (lvl == 0) {
                         if (ps < na) acc += w * (lp.p_MD * cur.m[ps] + lp.p_ID * cur.i[ps]);  // fd0, forward.rs:480-501
@@ -419,7 +432,7 @@ __global__ void __launch_bounds__(WFK_T) wide_forward_kernel(const SparseFwdArgs
         }
         // rescale so that the column maximum is in [0.5, 1)
         const int n = cur.n;
-        const double mx = wf_block_max(sh, t < n ? fmax(ib_cur, fmax(fmax(cur.m[t], cur.i[t]), cur.d[t])) : ib_cur);
+        const double mx = wf_block_max(sh, par, t < n ? fmax(ib_cur, fmax(fmax(cur.m[t], cur.i[t]), cur.d[t])) : ib_cur);
         const int e = sp_exp_of(mx);
         const double sc = sp_pow2(-e);
         if (t < n) {

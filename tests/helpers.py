@@ -183,3 +183,45 @@ def scores_tie_aware(oracle_mod, got, want, recompute, tol=1e-6):
         else:
             raise AssertionError((int(b), float(got[b]), seen))
     return int(bad.size)
+
+
+def wide_class_vs_generic(arrays, reads):
+    """generate_mappings with the 448-thread 400-slot kernels (wide_fwd_kernel.h / wide_bwd_kernel.h) and with the
+    one-wave generic ones (PHMM_NO_WIDE_CLASS=1: the kernels every parity test of rounds 1-2 ran) on the same reads.
+    The two are the same algorithm statement by statement; what may differ is the last bit of a sum (fused multiply-adds
+    are placed per kernel).  -> dict: max |d ln P|, positions whose lists differ as SETS, max |d list ln p| over the
+    rest, max |d node usage|, flags of the call, seconds of the second call of each."""
+    import os
+    import time
+    import dbgphmm_amd as D
+
+    def run(no_wide):
+        os.environ["PHMM_NO_WIDE_CLASS"] = "1" if no_wide else "0"
+        try:
+            gm, rc = D.PHMMModel(arrays), D.ReadCollection(reads)
+            gm.generate_mappings(rc, None, True)
+            t0 = time.perf_counter()
+            mp, nf = gm.generate_mappings(rc, None, True)
+            dt = time.perf_counter() - t0
+            _, flags = rc.last_call_info()
+            return mp.read_logp()[1].copy(), [x.copy() for x in mp.arrays()], nf.copy(), flags.copy(), dt
+        finally:
+            os.environ.pop("PHMM_NO_WIDE_CLASS", None)
+
+    a, b = run(True), run(False)
+    (pa, na, la), (pb, nb, lb) = a[1], b[1]
+    bad, dmax = 0, 0.0
+    if not np.array_equal(pa, pb):
+        bad = int((np.diff(pa.astype(np.int64)) != np.diff(pb.astype(np.int64))).sum()) if pa.shape == pb.shape else len(pa)
+    elif np.array_equal(na, nb):
+        dmax = float(np.max(np.abs(la - lb), initial=0.0))
+    else:
+        for i in np.unique(np.searchsorted(pa, np.flatnonzero(na != nb), side="right") - 1):
+            s0, s1 = int(pa[i]), int(pa[i + 1])
+            if sorted(na[s0:s1].tolist()) != sorted(nb[s0:s1].tolist()):
+                bad += 1
+            else:
+                dmax = max(dmax, float(np.max(np.abs(np.sort(la[s0:s1]) - np.sort(lb[s0:s1])))))
+    return dict(d_logp=float(np.max(np.abs(a[0] - b[0]), initial=0.0)), list_positions_differing=bad, positions=len(pa) - 1,
+                d_list_logp=dmax, d_node_freq=float(np.max(np.abs(a[2] - b[2]), initial=0.0)), flags=a[3],
+                generic_s=a[4], wide_s=b[4])

@@ -15,7 +15,7 @@ import pytest
 
 import dbgphmm_amd as D
 from dbgphmm_amd import _ffi
-from helpers import compare_mappings_tie_aware, scores_tie_aware, subset_csr
+from helpers import compare_mappings_tie_aware, scores_tie_aware, subset_csr, wide_class_vs_generic
 from repeat_cases import dataset
 
 pytestmark = pytest.mark.gpu
@@ -173,3 +173,23 @@ def test_long_reads_on_a_short_unit_repeat(gpu_lib, oracle):
     mp2, _ = gm.generate_mappings(rc, None, True)
     from helpers import same_mappings
     assert same_mappings(mp.arrays(), mp2.arrays())
+
+
+def test_wide_class_is_the_generic_algorithm(gpu_lib):
+    """The 400-slot frontier class on a block of 448 threads (round 3: what the repeat datasets above run in) against
+    the one-wave generic kernels it restates, on the datasets that live in that class -- forced switches and the
+    truncation at 400 elements included (u20n200: two thirds of the reads): ln P per read, the lists and the node usage
+    agree to 1e-9; a last-bit difference may move an entry of a flat column across the ratio cut (a handful of
+    positions in 2e5)."""
+    from fuzz_cases import make_case
+    cases = [(f"{name} k=40", *dataset(name, 40, coverage=cov)[:2]) for name, cov in (("u20n200", 20), ("u20", 20), ("u100n100", 5))]
+    rng = np.random.default_rng(77)
+    for n in range(12):
+        c = make_case(rng, n)
+        cases.append((c["tag"], c["arrays"], c["reads"]))
+    for tag, arrays, reads in cases:
+        r = wide_class_vs_generic(arrays, reads)
+        print(f"\n{tag}: " + ", ".join(f"{k}={v:.3g}" if isinstance(v, float) else f"{k}={v}" for k, v in r.items() if k != "flags")
+              + f" flagged={int((r['flags'] != 0).sum())} forced={int(((r['flags'] & _ffi.PHMM_READ_FORCED_SWITCH) != 0).sum())}")
+        assert r["d_logp"] < 1e-9 and r["d_list_logp"] < 1e-9 and r["d_node_freq"] < 1e-6, (tag, r)
+        assert r["list_positions_differing"] <= max(0, 1e-4 * r["positions"]), (tag, r)
