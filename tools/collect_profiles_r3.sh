@@ -12,6 +12,7 @@ cp $S/cfg3_L10k_stats/stats_kernel_stats.csv $P/r3_cfg3_L10k_kernel_stats.csv
 cp $S/rep_bench.json $P/r3_rep_bench.json
 cp $S/rep_stats/stats_kernel_stats.csv $P/r3_rep_kernel_stats.csv
 cp $S/rep20_bench.json $P/r3_rep20_bench.json
+cp $S/rep20_stats/stats_kernel_stats.csv $P/r3_rep20_kernel_stats.csv
 cp $S/cfg2_bench.json $P/r3_cfg2_bench.json
 cp $S/cand64_bench.json $P/r3_cand64_bench.json
 cp $S/cand256_bench.json $P/r3_cand256_bench.json

@@ -23,6 +23,7 @@ echo cfg3 sq done
 if [ "$1" != "quick" ]; then
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/cfg3_L10k_stats -o stats -- python3 $REPO/bench.py --read-len 10000 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/cfg3_L10k_bench_under_rocprof.json 2> $OUT/cfg3_L10k_stats.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/rep_stats -o stats -- python3 $REPO/bench.py --workload rep --steps 3 --warmup 1 --no-cpu-baseline > $OUT/rep_bench_under_rocprof.json 2> $OUT/rep_stats.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/rep20_stats -o stats -- python3 $REPO/bench.py --workload rep20 --steps 2 --warmup 2 --no-cpu-baseline > $OUT/rep20_bench_under_rocprof.json 2> $OUT/rep20_stats.err
 echo long-read stats done
 fi
 cd $REPO
