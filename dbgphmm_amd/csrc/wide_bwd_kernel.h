@@ -38,6 +38,7 @@ struct WideBwdShared {
     double red[2][8];
     int wsum[2][8];
     unsigned long long bc;
+    LinParams lp;  // (read from here: the scalar registers are short)
 };
 
 __device__ __forceinline__ uint32_t wb_hash(uint32_t id) { return (id * 2654435761u) >> 22; }
@@ -182,7 +183,9 @@ __global__ void __launch_bounds__(WBK_T) wide_backward_kernel(const SparseBwdArg
     const uint64_t p0 = a.lane_pos0[gi];
     const uint64_t q0 = a.map_pos0[gi];
     const double logP = a.d.logPf[gi];
-    const LinParams &lp = a.M.lp;
+    if (t == 0) sh.lp = a.M.lp;
+    __syncthreads();
+    const LinParams &lp = sh.lp;
     uint32_t err = 0;
     int par = 0;
     const bool ok = logP > -INFINITY;

@@ -29,8 +29,8 @@ static constexpr int WFK_HASH = 2048;  // 400 elements + the 448 candidates of t
 static_assert(WFK_CAP <= WFK_T && WFK_CAP + WFK_T < WFK_HASH, "slot / hash sizes");
 
 struct WCol {
-    double m[WFK_T], i[WFK_T], d[WFK_T];
-    uint32_t id[WFK_T];
+    double m[WFK_CAP], i[WFK_CAP], d[WFK_CAP];  // (slots: a column never holds more than 400 elements)
+    uint32_t id[WFK_CAP];
     uint32_t hkey[WFK_HASH];
     uint16_t hslot[WFK_HASH];
     int n, na, E;
@@ -48,6 +48,7 @@ struct WideFwdShared {
     int wsum[2][8];
     double red[2][8];
     unsigned long long bc;
+    LinParams lp;  // (read from here: thirteen doubles fewer in scalar registers, which the kernel was spilling)
 };
 
 __device__ __forceinline__ uint32_t wf_hash(uint32_t id) { return (id * 2654435761u) >> 21; }
@@ -218,7 +219,8 @@ __global__ void __launch_bounds__(WFK_T) wide_forward_kernel(const SparseFwdArgs
     const int s0 = a.sw[gi];
     const size_t NW = (size_t)a.d.N * a.W;
     const uint64_t p0 = a.lane_pos0[gi];
-    const LinParams &lp = a.M.lp;
+    if (t == 0) sh.lp = a.M.lp;
+    const LinParams &lp = sh.lp;
     int par = 0;
     uint32_t tag = 0xfffffe00u;  // batch tag of the arbitration cells (wf_append)
     for (int h = t; h < WFK_HASH; h += WFK_T) sh.arb[h] = 0xffffffffu;
