@@ -290,6 +290,9 @@ def main():
     ap.add_argument("--mode", choices=("mapping", "candidates", "map_nodes"), default="mapping")
     ap.add_argument("--candidates", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spin-up", type=float, default=2.0,
+                    help="seconds of extra UNTIMED steps behind the warm-up (not part of --warmup or --steps): the first "
+                         "GPU process on a fresh box runs its first seconds of steps 10-15 %% slower than a warm one")
     ap.add_argument("--read-len", type=int, default=0, help="override the workload's read length (e.g. 10000: HiFi)")
     args = ap.parse_args()
 
@@ -451,6 +454,30 @@ def main():
             torch.cuda.synchronize()
             first_ms = (time.perf_counter() - t0) * 1e3
     torch.cuda.synchronize()
+    # spin-up (untimed): measured on cfg3 with the same build on one fresh box -- first process with --warmup 1
+    # 252-256 ms per step, with --warmup 6 215 ms, every later process 220 ms whatever its warm-up.  A step of a big
+    # workload (cfg5: 28 s) warms the device by itself: nothing is added when the warm-up took that long already.
+    warm_s = time.perf_counter() - t0
+    spin_steps = 0
+
+    def agree(x):
+        """the ranks' mean of x: the same number on every rank (a step holds an all-reduce: the count must agree)"""
+        if dist is None:
+            return float(x)
+        v = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        PD.all_reduce_partial(v, dist)
+        return float(v.item()) / world
+
+    if agree(1.0 if (args.spin_up > 0 and warm_s < 12.0) else 0.0) == 1.0:
+        t_spin = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        dt1 = max(time.perf_counter() - t_spin, 1e-3)
+        more = int(agree(min(11.0, max(0.0, np.ceil(args.spin_up / dt1) - 1.0))))
+        for _ in range(more):
+            step()
+        torch.cuda.synchronize()
+        spin_steps = 1 + more
     if dist is not None:
         dist.barrier()
     state["ar_ms"] = 0.0
@@ -575,7 +602,7 @@ def main():
                            "parallelism": f"one read set sharded over {world} GPU(s) by bases; one all-reduce of [sum lnP, node_freq[N]]"
                            if args.scaling == "strong" or world == 1 else
                            f"{world} GPU(s), each with its own 20x read set; one all-reduce of [sum lnP, node_freq[N]]",
-                           "first_call_ms": first_ms, "per_rank_ms": per_rank_ms,
+                           "first_call_ms": first_ms, "spin_up_steps": spin_steps, "per_rank_ms": per_rank_ms,
                            "all_reduce_ms_per_step": state["ar_ms"] / max(args.steps, 1), "backend": backend, **extra},
                 "roofline": {"bound": "hbm", "achieved": rb["achieved"] if rb else 0.0, "peak": 8000.0, "unit": "GB/s",
                              "frac": (rb["achieved"] / 8000.0) if rb else 0.0, "traffic": traffic, "traffic_unit": "bytes/launch",
