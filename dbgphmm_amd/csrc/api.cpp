@@ -131,7 +131,45 @@ DevicePool &device_pool() {
     }
     return *g_pools[dev];
 }
+void DevicePool::recycle(DevBuf &b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(spare_mu);
+    if (b.bytes < ((size_t)1 << 20) || spare.size() >= SPARE_MAX || spare_total + b.bytes > SPARE_BYTES) {
+        b.release();
+        return;
+    }
+    spare_total += b.bytes;
+    const size_t n = b.bytes;
+    spare.emplace_back(b.detach(), n);
+}
+void DevicePool::take(DevBuf &b, size_t n) {
+    if (n <= b.bytes) return;
+    {
+        std::lock_guard<std::mutex> lk(spare_mu);
+        int best = -1;
+        for (int i = 0; i < (int)spare.size(); i++)
+            if (spare[i].second >= n && spare[i].second <= 2 * n + ((size_t)1 << 20) &&
+                (best < 0 || spare[i].second < spare[best].second))
+                best = i;
+        if (best >= 0) {
+            b.adopt(spare[best].first, spare[best].second);
+            spare_total -= spare[best].second;
+            spare.erase(spare.begin() + best);
+            return;
+        }
+    }
+    b.reserve(n);
+}
+void DevicePool::flush_spares() {
+    std::lock_guard<std::mutex> lk(spare_mu);
+    for (auto &e : spare) (void)hipFree(e.first);
+    spare.clear();
+    spare_total = 0;
+}
+void flush_spare_buffers() { device_pool().flush_spares(); }
+
 void DevicePool::release() {
+    flush_spares();
     for (auto &w : wsets) w.release();
     ws_out.release();
     for (auto &ws : wstream)
@@ -564,7 +602,21 @@ int phmm_mappings_export(const phmm_mappings *mp, uint64_t *pos_off, uint32_t *n
         if (logp) std::memcpy(logp, mp->logp.data(), mp->logp.size() * sizeof(double));
     });
 }
-void phmm_mappings_destroy(phmm_mappings *mp) { delete mp; }
+void phmm_mappings_destroy(phmm_mappings *mp) {
+    if (!mp) return;
+    // the device CSR goes back to its device's pool (a spare for the next generate_mappings call)
+    int dev = -1;
+    if (mp->device >= 0 && hipGetDevice(&dev) == hipSuccess && dev == mp->device) {
+        try {
+            DevicePool &pool = device_pool();
+            pool.recycle(mp->d_nodes);
+            pool.recycle(mp->d_logp);
+            pool.recycle(mp->d_pos_off);
+        } catch (...) {
+        }
+    }
+    delete mp;
+}
 
 int phmm_mappings_read_logp(const phmm_mappings *mp, double *out_logp, double *out_total) {
     return guarded([&] {

@@ -1187,10 +1187,12 @@ static void finish_mappings(phmm_model *m, const phmm_reads *reads, MappingSink 
     mp->read_logp = lf;
     mp->host_valid = false;
     mp->trusted = true;
+    (void)hipGetDevice(&mp->device);
+    DevicePool &dpool = device_pool();
     // counts -> exclusive scan -> compaction, all on the device
     DevBuf &cnt = m->wset().aux[13], &tmp = m->wset().aux[14];
     cnt.reserve(sizeof(uint64_t) * (n_pos + 1));
-    mp->d_pos_off.reserve(sizeof(uint64_t) * (n_pos + 1));
+    dpool.take(mp->d_pos_off, sizeof(uint64_t) * (n_pos + 1));
     const unsigned nb = (unsigned)((n_pos + 1 + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(map_counts, dim3(nb), dim3(BLOCK), 0, s, sink.mp, n_pos, cnt.as<uint64_t>());
     size_t tb = 0;
@@ -1201,12 +1203,13 @@ static void finish_mappings(phmm_model *m, const phmm_reads *reads, MappingSink 
     HIP_CHECK(hipMemcpyAsync(&total, mp->d_pos_off.as<uint64_t>() + n_pos, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     mp->total_entries = total;
-    mp->d_nodes.reserve(sizeof(uint32_t) * std::max<uint64_t>(total, 1));
-    mp->d_logp.reserve(sizeof(double) * std::max<uint64_t>(total, 1));
+    dpool.take(mp->d_nodes, sizeof(uint32_t) * std::max<uint64_t>(total, 1));
+    dpool.take(mp->d_logp, sizeof(double) * std::max<uint64_t>(total, 1));
     hipLaunchKernelGGL(map_compact, dim3(nb), dim3(BLOCK), 0, s, sink.mp, n_pos, mp->d_pos_off.as<uint64_t>(),
                        mp->d_nodes.as<uint32_t>(), mp->d_logp.as<double>());
     // longest list per read (capacity class of the hinted kernel)
-    DevBuf d_roff, d_rmax;
+    // (scratch of this function: workspace buffers, not a hipMalloc / hipFree pair per call)
+    DevBuf &d_roff = m->wset().aux[15], &d_rmax = m->wset().aux[16];
     d_roff.upload(reads->off.data(), sizeof(uint64_t) * (reads->R + 1));
     d_rmax.reserve(sizeof(uint32_t) * reads->R);
     hipLaunchKernelGGL(map_read_max, dim3((unsigned)((reads->R + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, s,
@@ -1217,7 +1220,7 @@ static void finish_mappings(phmm_model *m, const phmm_reads *reads, MappingSink 
     mp->on_device = true;
     trace("device CSR");
     if (out_node_freq) {
-        DevBuf d_prob, d_sn, d_sp, d_freq;
+        DevBuf &d_prob = m->wset().aux[17], &d_sn = m->wset().aux[18], &d_sp = m->wset().aux[19], &d_freq = m->wset().aux[20];
         const uint64_t n = std::max<uint64_t>(total, 1);
         d_prob.reserve(sizeof(double) * n);
         d_sn.reserve(sizeof(uint32_t) * n);

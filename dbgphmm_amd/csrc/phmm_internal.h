@@ -50,6 +50,7 @@ uint64_t table_budget(const DevicePool &pool, uint64_t reserve = 0);
 uint64_t planned_budget(const DevicePool &pool);
 
 // ---------------------------------------------------------------- device buffers
+void flush_spare_buffers();  // (api.cpp) frees the spare buffers of the current device's pool
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -66,8 +67,25 @@ struct DevBuf {
     void reserve(size_t n) {
         if (n <= bytes) return;
         release();
-        HIP_CHECK(hipMalloc(&p, n ? n : 1));
+        if (hipMalloc(&p, n ? n : 1) != hipSuccess) {
+            // the spare result buffers (DevicePool::recycle) are the one thing this library holds that nobody needs
+            (void)hipGetLastError();
+            p = nullptr;
+            flush_spare_buffers();
+            HIP_CHECK(hipMalloc(&p, n ? n : 1));
+        }
         bytes = n;
+    }
+    void adopt(void *q, size_t n) {
+        release();
+        p = q;
+        bytes = n;
+    }
+    void *detach() {
+        void *q = p;
+        p = nullptr;
+        bytes = 0;
+        return q;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
     void upload(const void *src, size_t n) {
@@ -83,7 +101,7 @@ void copy_out(void *dst, const void *src_dev, size_t bytes);
 // their own streams); the API thread and single-stream paths use set 0.  aux[] = per-call scratch kept across
 // calls (no hipMalloc in the steady state).  phmm_release_workspace() gives everything back.
 struct WorkSet {
-    DevBuf tables, misc, aux[16];
+    DevBuf tables, misc, aux[24];
     size_t bytes() const {
         size_t b = tables.bytes + misc.bytes;
         for (const auto &a : aux) b += a.bytes;
@@ -104,13 +122,24 @@ struct DevicePool {
     hipStream_t cstream[MAX_WORKERS] = {};  // per worker: side stream of the mapping-list kernels (mapping_flow.hip)
     hipEvent_t cevent[MAX_WORKERS][4] = {};
     DevBuf ws_out;
+    // The device buffers of destroyed phmm_mappings (their CSR: gigabytes on a tandem repeat), kept for the next
+    // generate_mappings call: a hipFree + hipMalloc pair per buffer and call otherwise (0.1-2 s per call on `rep20`,
+    // and it varies from box to box).  At most SPARE_MAX buffers / SPARE_BYTES; given back by release(), and by any
+    // allocation that fails (DevBuf::reserve).
+    static constexpr size_t SPARE_MAX = 6, SPARE_BYTES = (size_t)8 << 30;
+    std::mutex spare_mu;
+    std::vector<std::pair<void *, size_t>> spare;
+    size_t spare_total = 0;
+    void recycle(DevBuf &b);         // takes b's memory (frees it when the cache is full)
+    void take(DevBuf &b, size_t n);  // b.reserve(n), out of the cache when a spare of n .. 2n bytes is there
+    void flush_spares();
     size_t owned_table_bytes() const {
         size_t b = 0;
         for (const auto &w : wsets) b += w.tables.bytes;
         return b;
     }
     size_t owned_bytes() const {
-        size_t b = ws_out.bytes;
+        size_t b = ws_out.bytes + spare_total;
         for (const auto &w : wsets) b += w.bytes();
         return b;
     }
@@ -274,6 +303,7 @@ struct phmm_mappings {
     std::vector<uint32_t> read_max_list;  // [R] longest node list of each read
     std::vector<double> read_logp;        // [R] ln P(read) of the forward pass that produced the mappings (may be empty)
     mutable phmm::DevBuf d_pos_off, d_nodes, d_logp;
+    int device = -1;  // >= 0: the device whose pool takes the buffers back (phmm_mappings_destroy)
     mutable bool on_device = false;
     // Mappings produced by phmm_generate_mappings stay on the device (their next consumer is the
     // hinted forward kernel); the host vectors above are filled on first host access.
