@@ -74,8 +74,9 @@ int phmm_set_workspace_limit(uint64_t bytes);
 /* Workspaces (DP tables, record pools, scratch) belong to the DEVICE and are shared by every handle on it:
  * a mapping model and a scoring model can be alive together, as in multi_dbg/posterior.rs:247-255, 609-630
  * (the reference builds a fresh PModel per call and drops its tables on return).  They grow on demand and are
- * kept between calls; phmm_release_workspace() returns all of it to the device (the calling thread's current
- * device must be idle), phmm_workspace_bytes() says how much is held.  Calls that compute on one device are
+ * kept between calls; so are the device arrays of destroyed phmm_mappings (up to 6 buffers / 8 GB: the next
+ * phmm_generate_mappings call takes them instead of allocating).  phmm_release_workspace() returns all of it to the
+ * device (the calling thread's current device must be idle), phmm_workspace_bytes() says how much is held.  Calls that compute on one device are
  * serialised inside the library whatever handle or thread they come from. */
 int phmm_release_workspace(void);
 uint64_t phmm_workspace_bytes(void);

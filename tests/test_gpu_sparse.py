@@ -818,3 +818,30 @@ def test_overfull_dense_column_selection_paths_agree(gpu_lib, monkeypatch):
     po2, nd2, lp2 = mp2.arrays()
     assert np.array_equal(po1, po2) and np.array_equal(nd1, nd2) and np.array_equal(lp1, lp2)
     assert np.array_equal(nf1, nf2)
+
+
+def test_destroyed_mappings_leave_their_device_buffers_for_the_next_call(gpu_lib):
+    """The device CSR of a Mappings that is destroyed is kept by the device's pool (DevicePool::recycle: buffers of
+    1 MB and more, at most 6 / 8 GB) and handed to the next generate_mappings call instead of a hipFree + hipMalloc
+    pair; it counts as workspace and phmm_release_workspace() gives it back."""
+    from dbgphmm_amd import _ffi
+    L = _ffi.lib()
+    arrays, sg = small_dbg_model(3000, 16, 0.003, seed=33, min_copy_num=1)
+    reads = D.sample_reads(arrays, 10 ** 9, 400, seed=5, max_reads=150)
+    gm, rc = D.PHMMModel(arrays), D.ReadCollection(reads)
+    mp1, nf1 = gm.generate_mappings(rc, None, True)
+    a1 = [x.copy() for x in mp1.arrays()]
+    assert a1[2].nbytes >= 1 << 20  # (the ln p array is big enough to be kept)
+    held = L.phmm_workspace_bytes()
+    del mp1
+    spare = L.phmm_workspace_bytes() - held
+    assert spare >= a1[2].nbytes
+    mp2, nf2 = gm.generate_mappings(rc, None, True)
+    assert L.phmm_workspace_bytes() == held  # the spare went into mp2
+    assert same_mappings(a1, mp2.arrays()) and np.array_equal(nf1, nf2)
+    del mp2
+    assert L.phmm_workspace_bytes() == held + spare
+    _ffi.check(L.phmm_release_workspace())
+    assert L.phmm_workspace_bytes() == 0
+    mp3, _ = gm.generate_mappings(rc, None, True)
+    assert same_mappings(a1, mp3.arrays())
