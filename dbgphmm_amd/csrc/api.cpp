@@ -134,9 +134,15 @@ DevicePool &device_pool() {
 void DevicePool::recycle(DevBuf &b) {
     if (!b.p) return;
     std::lock_guard<std::mutex> lk(spare_mu);
-    if (b.bytes < ((size_t)1 << 20) || spare.size() >= SPARE_MAX || spare_total + b.bytes > SPARE_BYTES) {
+    if (b.bytes < ((size_t)1 << 20) || b.bytes > SPARE_BYTES) {
         b.release();
         return;
+    }
+    // the newest buffers stay (the next call most likely wants what the last one produced): the oldest go first
+    while (!spare.empty() && (spare.size() >= SPARE_MAX || spare_total + b.bytes > SPARE_BYTES)) {
+        (void)hipFree(spare.front().first);
+        spare_total -= spare.front().second;
+        spare.erase(spare.begin());
     }
     spare_total += b.bytes;
     const size_t n = b.bytes;
@@ -148,7 +154,7 @@ void DevicePool::take(DevBuf &b, size_t n) {
         std::lock_guard<std::mutex> lk(spare_mu);
         int best = -1;
         for (int i = 0; i < (int)spare.size(); i++)
-            if (spare[i].second >= n && spare[i].second <= 2 * n + ((size_t)1 << 20) &&
+            if (spare[i].second >= n && spare[i].second <= 2 * n &&
                 (best < 0 || spare[i].second < spare[best].second))
                 best = i;
         if (best >= 0) {

@@ -829,6 +829,7 @@ def test_destroyed_mappings_leave_their_device_buffers_for_the_next_call(gpu_lib
     arrays, sg = small_dbg_model(3000, 16, 0.003, seed=33, min_copy_num=1)
     reads = D.sample_reads(arrays, 10 ** 9, 400, seed=5, max_reads=150)
     gm, rc = D.PHMMModel(arrays), D.ReadCollection(reads)
+    _ffi.check(L.phmm_release_workspace())  # (spares of earlier tests in this process)
     mp1, nf1 = gm.generate_mappings(rc, None, True)
     a1 = [x.copy() for x in mp1.arrays()]
     assert a1[2].nbytes >= 1 << 20  # (the ln p array is big enough to be kept)
@@ -837,11 +838,16 @@ def test_destroyed_mappings_leave_their_device_buffers_for_the_next_call(gpu_lib
     spare = L.phmm_workspace_bytes() - held
     assert spare >= a1[2].nbytes
     mp2, nf2 = gm.generate_mappings(rc, None, True)
-    assert L.phmm_workspace_bytes() == held  # the spare went into mp2
+    assert L.phmm_workspace_bytes() - held < 1 << 16  # the spares went into mp2 (a hinted call may grow a control array)
     assert same_mappings(a1, mp2.arrays()) and np.array_equal(nf1, nf2)
     del mp2
-    assert L.phmm_workspace_bytes() == held + spare
+    assert spare <= L.phmm_workspace_bytes() - held < spare + (1 << 16)
     _ffi.check(L.phmm_release_workspace())
     assert L.phmm_workspace_bytes() == 0
     mp3, _ = gm.generate_mappings(rc, None, True)
     assert same_mappings(a1, mp3.arrays())
+    # the cache is bounded: the oldest spares go when more than six are waiting
+    keep = [gm.generate_mappings(rc, None, True)[0] for _ in range(5)]
+    held = L.phmm_workspace_bytes()
+    del keep, mp3
+    assert 0 < L.phmm_workspace_bytes() - held <= 6 * a1[2].nbytes
