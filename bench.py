@@ -611,6 +611,14 @@ def main():
                              **({k: v for k, v in rb.items() if k != "achieved"} if rb else {}),
                              "fwd_step": rf},
             }
+            fr = extra.get("frontier") or {}
+            if fr.get("share_list_gt64", 0.0) > 0.05:
+                # a wide-frontier workload (tandem repeat with a unit shorter than k): the step is the 400-slot frontier
+                # kernels', not the dense columns' -- say so next to the dense kernel's HBM line
+                out["roofline"]["note"] = ("most of this workload's step is wide_forward_kernel / wide_backward_kernel "
+                                           "(frontiers of 65-400 nodes: instruction-issue / barrier bound, SQ counters in "
+                                           "profiles/r3_rep20_sq_counters.txt); this object describes the dense warm-up's "
+                                           "bwd_step launches only")
             if not args.no_cpu_baseline and world == 1:
                 def gpu_check(sample):
                     return model.run_dense(D.ReadCollection(sample), False, False)[0]
